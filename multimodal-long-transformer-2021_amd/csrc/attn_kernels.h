@@ -1,0 +1,45 @@
+// Host <-> kernel parameter blocks and launcher prototypes (internal; the public
+// boundary is include/mmt_attn.h).
+#pragma once
+#include "mmt_common.h"
+
+namespace mmt {
+
+enum { kBand = 0, kDense = 1, kRows = 2 };
+
+struct FwdParams {
+  const void *q, *k, *v, *emb, *bias;
+  void* out;
+  float* lse;
+  const int32_t *att_mask, *rel_ids;  // dense mode
+  const int32_t* valid_len;
+  int B, S, N, R;
+  long qs[3], ks[3], vs[3], os[3];    // element strides of (b, s, n)
+  float sscale;    // scale * log2(e)                          (multiplies q.k)
+  float tscale;    // factor folded into the relative table (scale*log2e, or log2e)
+  float mask_add;  // mask_value * log2(e)
+  PatternDev pat;
+  int skip_global_rows;  // kBand: rows of global tokens are produced by the kRows pass
+  // dropout
+  uint32_t drop_thresh;  // keep iff hash >= thresh; 0 disables
+  uint32_t seed_lo, seed_hi;
+  float inv_keep;
+  // kRows
+  float* part_o;
+  float* part_ml;
+  int n_chunks, chunk_tiles, n_rowblk;
+};
+
+hipError_t launch_attn_fwd(const FwdParams& p, int mode, bool bf16, hipStream_t st);
+hipError_t launch_rows_combine(const FwdParams& p, bool bf16, hipStream_t st);
+
+struct SideParams {
+  PatternDev pat;
+  int B, S;
+  const int32_t *img_wp, *txt_wp;
+  int materialize_pattern;
+  int32_t *att_mask, *rel_ids, *segment_ids;
+};
+hipError_t launch_side_inputs(const SideParams& p, hipStream_t st);
+
+}  // namespace mmt

@@ -1,0 +1,199 @@
+// C ABI of the hot path (include/mmt_attn.h): validation, descriptor -> kernel parameter
+// translation, launches on the caller's stream.  No allocation, no synchronisation, no
+// global mutable state (the error message is thread-local).
+#include "../../include/mmt_attn.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "attn_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+constexpr int kChunkTiles = 8;  // kRows pass: 8 tiles = 256 keys per partial
+
+struct Plan {
+  bool dense;        // literal operator: att_mask / rel_ids from HBM
+  bool split_rows;   // structured pattern with global ROWS handled by the kRows pass
+  int n_rowblk, n_chunks;
+  size_t fwd_ws;     // bytes
+  size_t bwd_ws;
+};
+
+int check_desc(const mmt_attn_desc* d) {
+  if (!d) return fail(MMT_E_INVALID, "desc is NULL");
+  if (d->B <= 0 || d->S <= 0 || d->N <= 0) return fail(MMT_E_INVALID, "B,S,N must be positive");
+  if (d->D != 64) return fail(MMT_E_UNSUPPORTED, "D=%d: only head size 64 is built", d->D);
+  if (d->R < 0 || d->R > 64) return fail(MMT_E_UNSUPPORTED, "R=%d: relative vocab must be in [0,64]", d->R);
+  if (d->dtype != MMT_F32 && d->dtype != MMT_BF16) return fail(MMT_E_INVALID, "bad dtype %d", d->dtype);
+  const int64_t* st[4] = {d->q_stride, d->k_stride, d->v_stride, d->o_stride};
+  const int align = d->dtype == MMT_BF16 ? 8 : 4;  // 16-byte row loads
+  for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < 3; ++i)
+      if (st[t][i] < 0 || st[t][i] % align) return fail(MMT_E_INVALID, "strides must be non-negative multiples of %d elements", align);
+  if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return fail(MMT_E_INVALID, "dropout_p must be in [0,1)");
+  const mmt_mask_desc& m = d->mask;
+  if (m.local_radius < 0) return fail(MMT_E_INVALID, "local_radius must be >= 0");
+  if (m.n_global < 0 || m.global_start < 0 || m.global_start + m.n_global > d->S) return fail(MMT_E_INVALID, "global range outside the sequence");
+  if (m.id_mode < MMT_IDS_NONE || m.id_mode > MMT_IDS_2D) return fail(MMT_E_INVALID, "bad id_mode");
+  if (m.id_mode != MMT_IDS_NONE && m.max_dist < 0) return fail(MMT_E_INVALID, "max_dist must be >= 0");
+  if (m.id_mode == MMT_IDS_2D) {
+    if (m.patches_per_row <= 0 || m.core_layers <= 0) return fail(MMT_E_INVALID, "2-D ids need patches_per_row > 0 and core_layers > 0");
+    if ((int64_t)m.patches_per_row * m.patches_per_row > d->S) return fail(MMT_E_INVALID, "image part longer than the sequence");
+  }
+  return MMT_OK;
+}
+
+mmt::PatternDev make_pattern(const mmt_mask_desc& m, int S) {
+  mmt::PatternDev p;
+  p.radius = m.local_radius > S ? S : m.local_radius;
+  p.g0 = m.global_start;
+  p.ng = m.n_global;
+  p.id_mode = m.id_mode;
+  p.m = m.max_dist;
+  p.P = m.patches_per_row > 0 ? m.patches_per_row : 1;
+  p.r = m.core_layers;
+  p.I = m.id_mode == MMT_IDS_2D ? m.patches_per_row * m.patches_per_row : 0;
+  p.image_part = m.patches_per_row * m.patches_per_row + 8 + 2 * m.max_dist + 1;
+  p.text_part = p.image_part + 1;
+  return p;
+}
+
+Plan make_plan(const mmt_attn_desc* d, bool dense) {
+  Plan pl{};
+  pl.dense = dense;
+  const int n_tiles = (d->S + 31) / 32;
+  pl.split_rows = !dense && d->mask.n_global > 0 && d->mask.local_radius < d->S;
+  pl.n_rowblk = pl.split_rows ? (d->mask.n_global + 31) / 32 : 0;
+  pl.n_chunks = pl.split_rows ? (n_tiles + kChunkTiles - 1) / kChunkTiles : 0;
+  pl.fwd_ws = (size_t)d->B * d->N * pl.n_rowblk * pl.n_chunks * (32 * 64 + 64) * sizeof(float);
+  pl.bwd_ws = 0;
+  return pl;
+}
+
+void fill_common(mmt::FwdParams& p, const mmt_attn_desc* d) {
+  std::memset(&p, 0, sizeof(p));
+  p.B = d->B; p.S = d->S; p.N = d->N; p.R = d->R;
+  for (int i = 0; i < 3; ++i) {
+    p.qs[i] = d->q_stride[i]; p.ks[i] = d->k_stride[i];
+    p.vs[i] = d->v_stride[i]; p.os[i] = d->o_stride[i];
+  }
+  p.sscale = d->scale * mmt::kLog2e;
+  p.tscale = (d->flags & MMT_FLAG_SCALE_BEFORE_ADD) ? mmt::kLog2e : d->scale * mmt::kLog2e;
+  p.mask_add = d->mask_value * mmt::kLog2e;
+  p.pat = make_pattern(d->mask, d->S);
+  p.valid_len = d->mask.valid_len;
+  if (d->dropout_p > 0.f) {
+    double t = (double)d->dropout_p * 4294967296.0;
+    p.drop_thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    if (p.drop_thresh == 0) p.drop_thresh = 1;
+    p.inv_keep = 1.f / (1.f - d->dropout_p);
+    p.seed_lo = (uint32_t)d->dropout_seed;
+    p.seed_hi = (uint32_t)(d->dropout_seed >> 32);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mmt_abi_version(void) { return MMT_ABI_VERSION; }
+
+const char* mmt_last_error(void) { return g_err; }
+
+size_t mmt_workspace_bytes(const mmt_attn_desc* desc) {
+  if (check_desc(desc) != MMT_OK) return 0;
+  Plan pl = make_plan(desc, false);
+  return pl.fwd_ws > pl.bwd_ws ? pl.fwd_ws : pl.bwd_ws;
+}
+
+int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const void* v,
+                 const void* rel_emb, const void* rel_bias, const int32_t* att_mask,
+                 const int32_t* rel_ids, void* out, float* lse, void* workspace,
+                 size_t workspace_bytes, void* stream) {
+  if (int rc = check_desc(desc)) return rc;
+  if (!q || !k || !v || !out) return fail(MMT_E_INVALID, "q, k, v, out must not be NULL");
+  if (desc->R > 0 && !rel_emb) return fail(MMT_E_INVALID, "R > 0 but rel_emb is NULL");
+  const bool dense = att_mask != nullptr || rel_ids != nullptr;
+  const Plan pl = make_plan(desc, dense);
+  if (pl.fwd_ws > 0 && (!workspace || workspace_bytes < pl.fwd_ws))
+    return fail(MMT_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", pl.fwd_ws, workspace_bytes);
+
+  mmt::FwdParams p;
+  fill_common(p, desc);
+  p.q = q; p.k = k; p.v = v; p.emb = rel_emb; p.bias = rel_bias; p.out = out; p.lse = lse;
+  p.att_mask = att_mask; p.rel_ids = rel_ids;
+  if (desc->R == 0) { p.pat.id_mode = 0; p.rel_ids = nullptr; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool bf16 = desc->dtype == MMT_BF16;
+
+  hipError_t e;
+  if (dense) {
+    e = mmt::launch_attn_fwd(p, mmt::kDense, bf16, st);
+    if (e != hipSuccess) return fail(MMT_E_LAUNCH, "dense forward launch: %s", hipGetErrorString(e));
+    return MMT_OK;
+  }
+  p.skip_global_rows = pl.split_rows ? 1 : 0;
+  e = mmt::launch_attn_fwd(p, mmt::kBand, bf16, st);
+  if (e != hipSuccess) return fail(MMT_E_LAUNCH, "band forward launch: %s", hipGetErrorString(e));
+  if (pl.split_rows) {
+    p.n_rowblk = pl.n_rowblk; p.n_chunks = pl.n_chunks; p.chunk_tiles = kChunkTiles;
+    p.part_o = reinterpret_cast<float*>(workspace);
+    p.part_ml = p.part_o + (size_t)desc->B * desc->N * pl.n_rowblk * pl.n_chunks * (32 * 64);
+    e = mmt::launch_attn_fwd(p, mmt::kRows, bf16, st);
+    if (e != hipSuccess) return fail(MMT_E_LAUNCH, "global-rows forward launch: %s", hipGetErrorString(e));
+    e = mmt::launch_rows_combine(p, bf16, st);
+    if (e != hipSuccess) return fail(MMT_E_LAUNCH, "global-rows combine launch: %s", hipGetErrorString(e));
+  }
+  return MMT_OK;
+}
+
+int mmt_attn_bwd(const mmt_attn_desc* desc, const void*, const void*, const void*, const void*,
+                 const void*, const int32_t*, const int32_t*, const void*, const void*,
+                 const float*, void*, void*, void*, float*, float*, void*, size_t, void*) {
+  if (int rc = check_desc(desc)) return rc;
+  return fail(MMT_E_UNSUPPORTED, "mmt_attn_bwd: not built yet");
+}
+
+int mmt_side_inputs(const mmt_mask_desc* mask, int32_t B, int32_t S,
+                    const int32_t* num_image_wordpieces, const int32_t* num_text_wordpieces,
+                    int32_t materialize_pattern, int32_t* att_mask_out, int32_t* rel_ids_out,
+                    int32_t* segment_ids_out, void* stream) {
+  if (!mask) return fail(MMT_E_INVALID, "mask desc is NULL");
+  if (B <= 0 || S <= 0) return fail(MMT_E_INVALID, "B and S must be positive");
+  if (mask->id_mode < MMT_IDS_NONE || mask->id_mode > MMT_IDS_2D) return fail(MMT_E_INVALID, "bad id_mode");
+  if (mask->id_mode == MMT_IDS_2D) {
+    // same argument errors as MmtRelativePositionGenerator.__init__ (feature_utils.py:60-65)
+    if (mask->patches_per_row <= 0) return fail(MMT_E_INVALID, "`num_patch_per_row` must be positive.");
+    if (mask->core_layers <= 0) return fail(MMT_E_INVALID, "`num_core_layers` must be positive.");
+    if ((int64_t)mask->patches_per_row * mask->patches_per_row > S) return fail(MMT_E_INVALID, "image part longer than the sequence");
+  }
+  if (mask->id_mode != MMT_IDS_NONE && mask->max_dist < 0) return fail(MMT_E_INVALID, "`text_relative_pos_max_distance` must be positive.");
+  if (rel_ids_out && mask->id_mode == MMT_IDS_NONE) return fail(MMT_E_INVALID, "rel_ids_out requested with id_mode NONE");
+  if (materialize_pattern && (mask->local_radius < 0 || mask->n_global < 0 || mask->global_start < 0 ||
+                              mask->global_start + mask->n_global > S))
+    return fail(MMT_E_INVALID, "bad pattern");
+  mmt::SideParams p;
+  p.pat = make_pattern(*mask, S);
+  p.B = B; p.S = S;
+  p.img_wp = num_image_wordpieces; p.txt_wp = num_text_wordpieces;
+  p.materialize_pattern = materialize_pattern;
+  p.att_mask = att_mask_out; p.rel_ids = rel_ids_out; p.segment_ids = segment_ids_out;
+  hipError_t e = mmt::launch_side_inputs(p, reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(MMT_E_LAUNCH, "side inputs launch: %s", hipGetErrorString(e));
+  return MMT_OK;
+}
+
+}  // extern "C"

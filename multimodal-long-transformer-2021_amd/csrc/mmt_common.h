@@ -1,0 +1,115 @@
+// Shared device-side definitions for the gfx950 relative-attention kernels.
+//
+// Fragment conventions used throughout (CDNA4 32x32 MFMA, wave64):
+//   lane l -> r = l & 31 (row/col owned by the lane), h = l >> 5 (half).
+//   A 32x32 accumulator register i of lane (r,h) is element
+//       [row = kap(i,h)][col = r],   kap(i,h) = (i & 3) + 8 * (i >> 2) + 4 * h.
+//   Scores are computed "swapped" (S^T = K . Q^T) so that col = query row: every lane
+//   owns ONE query row and its 16 registers walk 16 keys; the softmax state (m, l) and the
+//   O^T accumulator (col = query row as well) are then lane-local.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mmt {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ int kap(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------------
+// Pattern + relative-id descriptor, device copy of mmt_mask_desc with derived constants.
+// ---------------------------------------------------------------------------------------
+struct PatternDev {
+  int radius;      // local radius W (>= S: no band)
+  int g0, ng;      // global tokens [g0, g0+ng)
+  int id_mode;     // 0 none, 1 = 1-D, 2 = 2-D
+  int m;           // relative_pos_max_distance
+  int P, r;        // patches per row, core layers (2-D)
+  int I;           // P*P image positions (2-D), 0 otherwise
+  int image_part;  // P*P + 8 + 2m + 1   (feature_utils.py:78-79)
+  int text_part;   // image_part + 1     (feature_utils.py:82)
+};
+
+// 1-D clipped id (etcmodel RelativePositionGenerator).
+__device__ __forceinline__ int id_1d(int q, int k, int m) {
+  int d = k - q;
+  int a = min(abs(d), m);
+  return d >= 0 ? a : m + a;
+}
+
+// 2-D id: value of the reference's base tensor at [P + dx, P + dy]
+// (feature_utils.py:89-112, 164-170) in closed form.
+__device__ __forceinline__ int id_2d(int dx, int dy, int r) {
+  const int d = 2 * r + 1;
+  const int vert = dx < -r ? 0 : (dx > r ? 2 : 1);
+  const int horz = dy < -r ? 0 : (dy > r ? 2 : 1);
+  if (vert == 1 && horz == 1) {
+    int c = dx * d + dy;
+    return c < 0 ? c + d * d : c;
+  }
+  // {top, top_right, right, right_bottom, bottom, bottom_left, left, top_left} = d*d + 0..7
+  // packed as nibbles indexed by vert*3+horz: (0,0)=7 (0,1)=0 (0,2)=1 (1,0)=6 (1,1)=x (1,2)=2
+  // (2,0)=5 (2,1)=4 (2,2)=3
+  const unsigned long long lut = 0x345206107ull;
+  return d * d + (int)((lut >> (4 * (vert * 3 + horz))) & 0xF);
+}
+
+__device__ __forceinline__ int rel_id(const PatternDev& p, int q, int k) {
+  if (p.id_mode == 1) return id_1d(q, k, p.m);
+  // id_mode == 2  (feature_utils.py:172-184)
+  const bool qi = q < p.I, ki = k < p.I;
+  if (qi && ki) {
+    const int xq = q / p.P, yq = q - xq * p.P;
+    const int xk = k / p.P, yk = k - xk * p.P;
+    return id_2d(xk - xq, yk - yq, p.r);
+  }
+  if (qi) return p.text_part;
+  if (ki) return p.image_part;
+  return id_1d(q, k, p.m);
+}
+
+__device__ __forceinline__ bool is_global(const PatternDev& p, int x) {
+  return (unsigned)(x - p.g0) < (unsigned)p.ng;
+}
+
+// mask(q,k) = segmented(q,k) && (|q-k| <= W || global(q) || global(k))   
+__device__ __forceinline__ bool pattern_mask(const PatternDev& p, int valid_len, int q, int k) {
+  const bool seg = (q < valid_len) == (k < valid_len);
+  const bool near = abs(q - k) <= p.radius;
+  return seg && (near || is_global(p, q) || is_global(p, k));
+}
+
+// ---------------------------------------------------------------------------------------
+// Dropout keep decision shared by forward and backward (and restated on the CPU in the
+// tests): one 32-bit mix per (b, n, q, k).  keep iff hash >= threshold.
+// ---------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_hash(uint32_t seed_lo, uint32_t seed_hi,
+                                                          uint32_t bn, uint32_t q, uint32_t k) {
+  uint32_t a = mix32(seed_lo ^ (bn * 0x9E3779B9u));
+  uint32_t b = mix32(seed_hi + q * 0x85EBCA6Bu + a);
+  return mix32(b ^ (k * 0xC2B2AE35u));
+}
+
+// XCD-aware remap of a 1-D grid: consecutive logical ids land on the same XCD (blocks are
+// dealt round-robin over the 8 XCDs).  Speed only; identity when the grid is not a multiple
+// of 8.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  if (nwg & 7) return bid;
+  const int cpx = nwg >> 3;
+  return (bid & 7) * cpx + (bid >> 3);
+}
+
+}  // namespace mmt

@@ -1,0 +1,54 @@
+// Integer side inputs on the device, bit-exact with the reference's tf.data stage
+// (src/data/data_utils.py:335-379; src/feature_utils.py:114-184; etcmodel 1-D ids and
+// make_segmented_att_mask per SURVEY.md App. A.2).  HBM-write-bound: one int4 store per
+// lane per output, rows walked by a grid-stride loop.
+#include "attn_kernels.h"
+
+namespace mmt {
+
+__global__ __launch_bounds__(256) void side_inputs_kernel(const SideParams p) {
+  const int S = p.S;
+  const long row_chunks = (S + 3) >> 2;                 // int4 chunks per row
+  const long total = (long)p.B * S * row_chunks;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long rowid = idx / row_chunks;
+    const int k0 = (int)(idx - rowid * row_chunks) * 4;
+    const int b = (int)(rowid / S), q = (int)(rowid - (long)b * S);
+    const int img = p.img_wp ? p.img_wp[b] : S, txt = p.txt_wp ? p.txt_wp[b] : 0;
+    const int valid = img + txt;
+    int mv[4], iv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + j;
+      bool keep = (q < valid) == (k < valid);            // data_utils.py:321-322
+      if (p.materialize_pattern) keep = pattern_mask(p.pat, valid, q, k);
+      mv[j] = keep ? 1 : 0;
+      iv[j] = p.pat.id_mode ? rel_id(p.pat, q, k) : 0;
+    }
+    const long off = rowid * S + k0;
+    if ((S & 3) == 0) {
+      if (p.att_mask) *reinterpret_cast<i32x4*>(p.att_mask + off) = i32x4{mv[0], mv[1], mv[2], mv[3]};
+      if (p.rel_ids) *reinterpret_cast<i32x4*>(p.rel_ids + off) = i32x4{iv[0], iv[1], iv[2], iv[3]};
+    } else {
+      for (int j = 0; j < 4 && k0 + j < S; ++j) {
+        if (p.att_mask) p.att_mask[off + j] = mv[j];
+        if (p.rel_ids) p.rel_ids[off + j] = iv[j];
+      }
+    }
+    if (p.segment_ids && k0 == 0) {                      // data_utils.py:350-361
+      p.segment_ids[rowid] = (q < img ? 1 : 0) + ((q > img && q < img + txt) ? 2 : 0);
+    }
+  }
+}
+
+hipError_t launch_side_inputs(const SideParams& p, hipStream_t st) {
+  const long total = (long)p.B * p.S * ((p.S + 3) / 4);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(side_inputs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+}  // namespace mmt

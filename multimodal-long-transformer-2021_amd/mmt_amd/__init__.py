@@ -1,0 +1,9 @@
+"""mmt_amd -- MI355X-native hot path of googleinterns/multimodal-long-transformer-2021.
+
+Host-side mirror (Python, like the reference) of the relative-attention path of
+`MmtEncoder`, over a C ABI (include/mmt_attn.h) into hand-written HIP kernels for gfx950.
+"""
+from . import _lib
+from .ops import AttentionPattern, relative_attention_forward, side_inputs
+
+__all__ = ['AttentionPattern', 'relative_attention_forward', 'side_inputs', '_lib']

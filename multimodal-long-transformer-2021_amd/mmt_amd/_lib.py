@@ -1,0 +1,98 @@
+"""ctypes binding of the C ABI declared in include/mmt_attn.h.
+
+The shared library is built in-tree (csrc/Makefile -> mmt_amd/libmmt_attn.so).  There is
+no CPU fallback: if the library is missing, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
+LIB_PATH = os.path.join(_HERE, 'libmmt_attn.so')
+
+MMT_ABI_VERSION = 1
+MMT_F32, MMT_BF16 = 0, 1
+MMT_IDS_NONE, MMT_IDS_1D, MMT_IDS_2D = 0, 1, 2
+MMT_FLAG_SCALE_BEFORE_ADD = 1
+
+EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn_fwd',
+           'mmt_attn_bwd', 'mmt_side_inputs')
+
+
+class MaskDesc(ctypes.Structure):
+  _fields_ = [('valid_len', ctypes.c_void_p), ('local_radius', ctypes.c_int32),
+              ('global_start', ctypes.c_int32), ('n_global', ctypes.c_int32),
+              ('id_mode', ctypes.c_int32), ('max_dist', ctypes.c_int32),
+              ('patches_per_row', ctypes.c_int32), ('core_layers', ctypes.c_int32)]
+
+
+class AttnDesc(ctypes.Structure):
+  _fields_ = [('B', ctypes.c_int32), ('S', ctypes.c_int32), ('N', ctypes.c_int32),
+              ('D', ctypes.c_int32), ('R', ctypes.c_int32), ('dtype', ctypes.c_int32),
+              ('q_stride', ctypes.c_int64 * 3), ('k_stride', ctypes.c_int64 * 3),
+              ('v_stride', ctypes.c_int64 * 3), ('o_stride', ctypes.c_int64 * 3),
+              ('scale', ctypes.c_float), ('mask_value', ctypes.c_float),
+              ('flags', ctypes.c_uint32), ('dropout_p', ctypes.c_float),
+              ('dropout_seed', ctypes.c_uint64), ('mask', MaskDesc)]
+
+
+class MmtError(RuntimeError):
+  """Raised when an entry point of libmmt_attn returns a negative code."""
+
+  def __init__(self, code: int, message: str):
+    super().__init__(f'libmmt_attn error {code}: {message}')
+    self.code = code
+
+
+def build(force: bool = False) -> str:
+  """Compiles the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+  srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(('.hip', '.h'))]
+  srcs.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), 'include', 'mmt_attn.h'))
+  stale = (not os.path.exists(LIB_PATH) or
+           any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs))
+  if force or stale:
+    subprocess.check_call(['make', '-s', '-j4', '-C', _CSRC])
+  return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f'{LIB_PATH} is missing: the HIP extension has not been built '
+        '(run `python -c "import __graft_entry__ as g; g.build()"` or `make -C csrc`). '
+        'There is no CPU fallback for the hot path.')
+  L = ctypes.CDLL(LIB_PATH)
+  vp, i32p = ctypes.c_void_p, ctypes.c_void_p
+  L.mmt_abi_version.restype = ctypes.c_int
+  L.mmt_abi_version.argtypes = []
+  L.mmt_last_error.restype = ctypes.c_char_p
+  L.mmt_last_error.argtypes = []
+  L.mmt_workspace_bytes.restype = ctypes.c_size_t
+  L.mmt_workspace_bytes.argtypes = [ctypes.POINTER(AttnDesc)]
+  L.mmt_attn_fwd.restype = ctypes.c_int
+  L.mmt_attn_fwd.argtypes = [ctypes.POINTER(AttnDesc), vp, vp, vp, vp, vp, i32p, i32p, vp, vp,
+                             vp, ctypes.c_size_t, vp]
+  L.mmt_attn_bwd.restype = ctypes.c_int
+  L.mmt_attn_bwd.argtypes = [ctypes.POINTER(AttnDesc), vp, vp, vp, vp, vp, i32p, i32p, vp, vp, vp,
+                             vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]
+  L.mmt_side_inputs.restype = ctypes.c_int
+  L.mmt_side_inputs.argtypes = [ctypes.POINTER(MaskDesc), ctypes.c_int32, ctypes.c_int32, i32p,
+                                i32p, ctypes.c_int32, i32p, i32p, i32p, vp]
+  if L.mmt_abi_version() != MMT_ABI_VERSION:
+    raise ImportError('libmmt_attn ABI version mismatch')
+  _lib = L
+  return L
+
+
+def check(rc: int) -> None:
+  if rc != 0:
+    raise MmtError(rc, lib().mmt_last_error().decode())

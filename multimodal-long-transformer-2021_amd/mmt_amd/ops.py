@@ -1,0 +1,159 @@
+"""Host side of the hot path: torch tensors as buffer carriers over the C ABI.
+
+`relative_attention` is the operator `etcmodel.layers.attention.QkvRelativeAttention`
+computes inside `RelativeTransformerLayers` (reference call site
+src/modeling/models/mmt_encoder.py:220-224; math SURVEY.md App. A.3).  Two input forms:
+
+  * dense   : `att_mask`, `relative_att_ids` int32 [B,S,S] exactly as the reference feeds
+              them (literal operator);
+  * pattern : an `AttentionPattern` descriptor -- mask and ids are generated in-kernel and
+              never materialised (the long-sequence fast path).
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+
+@dataclasses.dataclass(frozen=True)
+class AttentionPattern:
+  """Structured mask + relative-id generator (mirrors `mmt_mask_desc`).
+
+  local_radius >= seq_len with n_global == 0 is the reference's segmented mask
+  (src/data/data_utils.py:321-322); id_mode 1 is the etcmodel 1-D generator
+  (data_utils.py:300-301), id_mode 2 `MmtRelativePositionGenerator`
+  (src/feature_utils.py:29).
+  """
+  local_radius: int = 1 << 30
+  global_start: int = 0
+  n_global: int = 0
+  id_mode: int = _lib.MMT_IDS_1D
+  max_dist: int = 12
+  patches_per_row: int = 0
+  core_layers: int = 0
+
+  def to_desc(self, valid_len: Optional[torch.Tensor] = None) -> _lib.MaskDesc:
+    m = _lib.MaskDesc()
+    m.valid_len = valid_len.data_ptr() if valid_len is not None else None
+    m.local_radius = min(int(self.local_radius), (1 << 31) - 1)
+    m.global_start, m.n_global = int(self.global_start), int(self.n_global)
+    m.id_mode, m.max_dist = int(self.id_mode), int(self.max_dist)
+    m.patches_per_row, m.core_layers = int(self.patches_per_row), int(self.core_layers)
+    return m
+
+
+def _stream_ptr(device) -> int:
+  return torch.cuda.current_stream(device).cuda_stream
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+  if t.dtype == torch.float32:
+    return _lib.MMT_F32
+  if t.dtype == torch.bfloat16:
+    return _lib.MMT_BF16
+  raise TypeError(f'relative_attention supports float32 and bfloat16, got {t.dtype}')
+
+
+def _strides(t: torch.Tensor):
+  if t.dim() != 4 or t.stride(3) != 1:
+    raise ValueError('q/k/v/out must be [B,S,N,D] views with a contiguous head dimension')
+  return (t.stride(0), t.stride(1), t.stride(2))
+
+
+def _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_before_add,
+               dropout_p, dropout_seed) -> _lib.AttnDesc:
+  B, S, N, D = q.shape
+  d = _lib.AttnDesc()
+  d.B, d.S, d.N, d.D, d.R = B, S, N, D, R
+  d.dtype = _dtype_code(q)
+  for name, t in (('q_stride', q), ('k_stride', k), ('v_stride', v), ('o_stride', out)):
+    getattr(d, name)[:] = _strides(t)
+  d.scale = float(scale if scale is not None else 1.0 / math.sqrt(D))
+  d.mask_value = float(mask_value)
+  d.flags = _lib.MMT_FLAG_SCALE_BEFORE_ADD if scale_before_add else 0
+  d.dropout_p = float(dropout_p)
+  d.dropout_seed = int(dropout_seed) & ((1 << 64) - 1)
+  d.mask = (pattern or AttentionPattern(id_mode=_lib.MMT_IDS_NONE)).to_desc(valid_len)
+  return d
+
+
+def _check_inputs(q, k, v, rel_emb, rel_bias, att_mask, rel_ids, valid_len):
+  if not q.is_cuda:
+    raise RuntimeError('relative_attention runs on the GPU only (no CPU fallback)')
+  for t in (k, v):
+    if t.shape != q.shape or t.dtype != q.dtype or t.device != q.device:
+      raise ValueError('q, k, v must agree in shape, dtype and device')
+  B, S, N, D = q.shape
+  R = 0
+  if rel_emb is not None:
+    if rel_emb.dim() != 3 or rel_emb.shape[1:] != (N, D) or rel_emb.dtype != q.dtype:
+      raise ValueError('rel_emb must be [R,N,D] in the dtype of q')
+    R = rel_emb.shape[0]
+    if not rel_emb.is_contiguous():
+      raise ValueError('rel_emb must be contiguous')
+    if rel_bias is not None and (rel_bias.shape != (R, N) or rel_bias.dtype != q.dtype
+                                 or not rel_bias.is_contiguous()):
+      raise ValueError('rel_bias must be contiguous [R,N] in the dtype of q')
+  for t in (att_mask, rel_ids):
+    if t is not None and (t.dtype != torch.int32 or t.shape != (B, S, S) or not t.is_contiguous()):
+      raise ValueError('att_mask / relative_att_ids must be contiguous int32 [B,S,S]')
+  if valid_len is not None and (valid_len.dtype != torch.int32 or valid_len.shape != (B,)
+                                or not valid_len.is_contiguous()):
+    raise ValueError('valid_len must be contiguous int32 [B]')
+  return R
+
+
+def relative_attention_forward(q, k, v, rel_emb=None, rel_bias=None, *, att_mask=None,
+                               relative_att_ids=None, pattern: Optional[AttentionPattern] = None,
+                               valid_len=None, scale=None, mask_value=-10000.0,
+                               scale_before_add=False, dropout_p=0.0, dropout_seed=0,
+                               return_lse=True):
+  """Forward only.  Returns (out [B,S,N,D] in q.dtype, lse fp32 [B,N,S])."""
+  R = _check_inputs(q, k, v, rel_emb, rel_bias, att_mask, relative_att_ids, valid_len)
+  dense = att_mask is not None or relative_att_ids is not None
+  if dense and pattern is not None:
+    raise ValueError('pass either dense att_mask/relative_att_ids or a pattern, not both')
+  B, S, N, D = q.shape
+  out = torch.empty((B, S, N, D), dtype=q.dtype, device=q.device)
+  lse = torch.empty((B, N, S), dtype=torch.float32, device=q.device) if return_lse else None
+  desc = _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_before_add,
+                    dropout_p, dropout_seed)
+  L = _lib.lib()
+  ws_bytes = 0 if dense else L.mmt_workspace_bytes(desc)
+  ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=q.device)
+  ptr = lambda t: None if t is None else t.data_ptr()
+  with torch.cuda.device(q.device):
+    _lib.check(L.mmt_attn_fwd(desc, ptr(q), ptr(k), ptr(v), ptr(rel_emb), ptr(rel_bias),
+                              ptr(att_mask), ptr(relative_att_ids), ptr(out), ptr(lse), ptr(ws),
+                              ws.numel(), _stream_ptr(q.device)))
+  return out, lse
+
+
+def side_inputs(pattern: AttentionPattern, num_image_wordpieces: torch.Tensor,
+                num_text_wordpieces: torch.Tensor, max_seq_len: int, *, want_mask=True,
+                want_ids=True, want_segment_ids=True, materialize_pattern=False):
+  """Device-side `add_side_input_features` (src/data/data_utils.py:335-379), batched.
+
+  Returns dict(segment_ids [B,S], att_mask [B,S,S], relative_att_ids [B,S,S]) int32.
+  """
+  if not num_image_wordpieces.is_cuda:
+    raise RuntimeError('side_inputs runs on the GPU only (no CPU fallback)')
+  dev = num_image_wordpieces.device
+  B, S = num_image_wordpieces.shape[0], int(max_seq_len)
+  img = num_image_wordpieces.to(torch.int32).contiguous()
+  txt = num_text_wordpieces.to(torch.int32).contiguous()
+  want_ids = want_ids and pattern.id_mode != _lib.MMT_IDS_NONE and pattern.max_dist > 0
+  mask = torch.empty((B, S, S), dtype=torch.int32, device=dev) if want_mask else None
+  ids = torch.empty((B, S, S), dtype=torch.int32, device=dev) if want_ids else None
+  seg = torch.empty((B, S), dtype=torch.int32, device=dev) if want_segment_ids else None
+  desc = pattern.to_desc(None)
+  ptr = lambda t: None if t is None else t.data_ptr()
+  with torch.cuda.device(dev):
+    _lib.check(_lib.lib().mmt_side_inputs(desc, B, S, ptr(img), ptr(txt), int(materialize_pattern),
+                                          ptr(mask), ptr(ids), ptr(seg), _stream_ptr(dev)))
+  return {'segment_ids': seg, 'att_mask': mask, 'relative_att_ids': ids}
