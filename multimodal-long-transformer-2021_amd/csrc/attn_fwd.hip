@@ -7,15 +7,16 @@
 //
 //   one wave = 32 query rows of one (batch, head); it walks 32-key tiles.
 //   S^T = K.Q^T by MFMA (keys in registers, query row on the lane), relative scores are
-//   gathered from a per-wave LDS table T[q][id] = (q.E[id] + bias[id]) built once per
+//   gathered from a per-wave LDS table T[q][col(id)] = (q.E[id] + bias[id]) built once per
 //   q-block by MFMA, softmax state is lane-local, O^T += V^T.P^T by MFMA with the P
 //   accumulator reused as the B operand (no LDS round trip for P) and V^T fragments read
-//   with ds_read_b64_tr_b16 from a wave-private, bank-swizzled LDS tile.
+//   with ds_read_b64_tr_b16 from a wave-private, bank-swizzled LDS tile.  The next tile's
+//   K fragments and V rows are prefetched into registers while the current tile computes.
 //
-// Modes
-//   kBand : structured pattern (band + global keys), ids/mask generated in-kernel   [K1]
-//   kDense: literal reference operator, att_mask / rel_ids int32 [B,S,S] from HBM   [K3]
-//   kRows : selected (global) query rows x a chunk of keys, partial (O,m,l) out     [K2]
+// Work items of one launch
+//   band items : 32 query rows x (band tiles U global-key tiles), final output        [K1]
+//   rows items : 32 global query rows x one chunk of keys, partial (O,m,l) output     [K2]
+//   (kDense)   : literal reference operator, att_mask / rel_ids int32 [B,S,S] from HBM [K3]
 #include "attn_kernels.h"
 
 namespace mmt {
@@ -26,14 +27,10 @@ template <typename T> struct Frag;
 // MFMA k-index (8h + j) of step s is mapped to head-dim d = 32h + 8s + j, so each lane
 // loads 64 contiguous bytes of its row (4 x 16 B).
 template <> struct Frag<__bf16> {
-  static constexpr int kSteps = 4;
   bf16x8 v[4];
-  __device__ __forceinline__ void load_row(const __bf16* row, int h, bool ok) {
+  __device__ __forceinline__ void load_row(const __bf16* row, int h) {
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (ok) v[s] = *reinterpret_cast<const bf16x8*>(row + 32 * h + 8 * s);
-      else v[s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    }
+    for (int s = 0; s < 4; ++s) v[s] = *reinterpret_cast<const bf16x8*>(row + 32 * h + 8 * s);
   }
 };
 __device__ __forceinline__ f32x16 mma_rows(const Frag<__bf16>& a, const Frag<__bf16>& b, f32x16 c) {
@@ -45,12 +42,11 @@ __device__ __forceinline__ f32x16 mma_rows(const Frag<__bf16>& a, const Frag<__b
 // ------------------------------- f32: 32x32x2 MFMA (exact f32) -----------------------
 // MFMA k-index h of step s is mapped to d = 32h + s: each lane loads 128 contiguous bytes.
 template <> struct Frag<float> {
-  static constexpr int kSteps = 32;
   float v[32];
-  __device__ __forceinline__ void load_row(const float* row, int h, bool ok) {
+  __device__ __forceinline__ void load_row(const float* row, int h) {
 #pragma unroll
     for (int s = 0; s < 32; s += 4) {
-      f32x4 t = ok ? *reinterpret_cast<const f32x4*>(row + 32 * h + s) : f32x4{0, 0, 0, 0};
+      f32x4 t = *reinterpret_cast<const f32x4*>(row + 32 * h + s);
       v[s] = t[0]; v[s + 1] = t[1]; v[s + 2] = t[2]; v[s + 3] = t[3];
     }
   }
@@ -61,11 +57,47 @@ __device__ __forceinline__ f32x16 mma_rows(const Frag<float>& a, const Frag<floa
   return c;
 }
 
-__device__ __forceinline__ float half_xchg(float x) {  // value held by lane ^ 32
-  return __shfl_xor(x, 32, 64);
-}
+// V rows of one tile held in registers between the global load and their use.
+template <typename T> struct VTile;
+template <> struct VTile<__bf16> {   // 4 x 16-B chunks per lane -> written to the LDS tile
+  bf16x8 c[4];
+  __device__ __forceinline__ void load(const __bf16* V, unsigned vs1, int k0, int S, int lane, int) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ci = lane + 64 * u, row = ci >> 3, ch = ci & 7;
+      const unsigned kk = (unsigned)min(k0 + row, S - 1);  // rows past the end repeat the last row; their p is 0
+      c[u] = *reinterpret_cast<const bf16x8*>(V + (kk * vs1 + (unsigned)ch * 8u));
+    }
+  }
+  // 32 rows x 128 B; the two 64-B halves of a row are swapped when bit 1 of the row is set,
+  // which makes the 4-row transposed reads below bank-conflict free.
+  __device__ __forceinline__ void to_lds(unsigned char* vlds, int lane) const {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ci = lane + 64 * u, row = ci >> 3, ch = ci & 7;
+      const int off = row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
+      *reinterpret_cast<bf16x8*>(vlds + off) = c[u];
+    }
+  }
+};
+template <> struct VTile<float> {    // A operand of the 32x32x2 PV product, straight from L2
+  float a0[16], a1[16];
+  __device__ __forceinline__ void load(const float* V, unsigned vs1, int k0, int S, int lane, int) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const unsigned kk = (unsigned)min(k0 + kap(s, h), S - 1);
+      const float* vr = V + kk * vs1;
+      a0[s] = vr[r]; a1[s] = vr[32 + r];
+    }
+  }
+  __device__ __forceinline__ void to_lds(unsigned char*, int) const {}
+};
+
+__device__ __forceinline__ float half_xchg(float x) { return __shfl_xor(x, 32, 64); }
 
 constexpr int kTStride(int Rp) { return Rp + 1; }
+constexpr float kRescaleThr = 6.0f;
 
 // LDS carve per wave: T table [32][Rp+1] f32, then (bf16 only) V tile 32 x 128 B.
 template <typename T, int Rp> struct WaveLds {
@@ -75,7 +107,17 @@ template <typename T, int Rp> struct WaveLds {
   static constexpr int kBytes = kTBytesAligned + kVBytes;
 };
 
-template <typename T, int MODE, int Rp>
+// Column of relative id `id` inside the LDS table.  For the 1-D generator the columns are
+// permuted so that column = clamp(k - q, -m, m) + m: the hot loop then needs no sign
+// handling (id <= m  <->  d = id;  m < id <= 2m  <->  d = m - id).
+__device__ __forceinline__ int tcol(int perm_1d, int m, int id) {
+  const int pc = id <= m ? m + id : 2 * m - id;
+  return ((perm_1d != 0) & (id <= 2 * m)) ? pc : id;
+}
+
+// GEN = true: ids/mask through the generic per-element generators (2-D ids, or 1-D ids whose
+// vocabulary is smaller than 2m+1); GEN = false: no ids or 1-D ids with the permuted table.
+template <typename T, int MODE, int Rp, bool GEN>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -84,21 +126,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
   unsigned char* wl = smem + wave * WaveLds<T, Rp>::kBytes;
   float* tab = reinterpret_cast<float*>(wl);
   unsigned char* vlds = wl + WaveLds<T, Rp>::kTBytesAligned;
-  (void)vlds;
 
   // ---- which 32 query rows does this wave own? ------------------------------------
+  const int n_tiles = (p.S + 31) >> 5;
+  const int nqb = (p.S + 127) >> 7;
+  const bool rows_item = MODE == kBand && (int)blockIdx.x >= p.n_band_blocks;
   int bn, q0, chunk = 0, rowblk = 0;
-  if (MODE == kRows) {
-    // grid: ((n_chunks * n_rowblk + 3) / 4, B*N); one wave per (rowblk, chunk)
-    const int item = blockIdx.x * 4 + wave;
+  if (rows_item) {
+    const int per_bn = (p.n_chunks * p.n_rowblk + 3) >> 2;
+    const int rb = blockIdx.x - p.n_band_blocks;
+    bn = rb / per_bn;
+    const int item = (rb - bn * per_bn) * 4 + wave;
     if (item >= p.n_chunks * p.n_rowblk) return;
     rowblk = item / p.n_chunks;
     chunk = item - rowblk * p.n_chunks;
-    bn = blockIdx.y;
     q0 = p.pat.g0 + rowblk * 32;
   } else {
-    const int nqb = (p.S + 127) >> 7;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int wg = xcd_remap(blockIdx.x, p.n_band_blocks);
     bn = wg / nqb;
     q0 = (wg - bn * nqb) * 128 + wave * 32;
     if (q0 >= p.S) return;
@@ -111,116 +155,179 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
   const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)n * p.qs[2];
   const T* K = reinterpret_cast<const T*>(p.k) + (long)b * p.ks[0] + (long)n * p.ks[2];
   const T* V = reinterpret_cast<const T*>(p.v) + (long)b * p.vs[0] + (long)n * p.vs[2];
+  // row offsets inside one (b, n) plane fit 32 bits (checked on the host)
+  const unsigned qs1 = (unsigned)p.qs[1], ks1 = (unsigned)p.ks[1], vs1 = (unsigned)p.vs[1];
+
+  // ---- tile walk: [a0, a0+lenA) U [b0, b0+lenB) U [c0, c0+lenC), ascending ------------
+  int a0 = 0, lenA = 0, b0 = 0, lenB = n_tiles, c0 = 0, lenC = 0;
+  if (MODE == kBand) {
+    if (rows_item) {
+      b0 = chunk * p.chunk_tiles;
+      lenB = min(n_tiles, b0 + p.chunk_tiles) - b0;
+    } else {
+      const int lo = max(q0 - p.pat.radius, 0), hi = min(q0 + 31 + p.pat.radius, p.S - 1);
+      b0 = lo >> 5;
+      const int b1 = hi >> 5;
+      lenB = b1 - b0 + 1;
+      if (p.pat.ng > 0) {
+        const int g_lo = p.pat.g0 >> 5, g_hi = (p.pat.g0 + p.pat.ng - 1) >> 5;
+        a0 = g_lo; lenA = max(0, min(g_hi, b0 - 1) - g_lo + 1);
+        c0 = max(g_lo, b1 + 1); lenC = max(0, g_hi - c0 + 1);
+      }
+    }
+  }
+  const int n_it = lenA + lenB + lenC;
+  auto tile_at = [&](int it) {
+    return it < lenA ? a0 + it : (it < lenA + lenB ? b0 + (it - lenA) : c0 + (it - lenA - lenB));
+  };
 
   Frag<T> qf;
-  qf.load_row(Q + (long)(q_ok ? q : 0) * p.qs[1], h, q_ok);
+  qf.load_row(Q + (unsigned)min(q, p.S - 1) * qs1, h);
 
-  // ---- relative-score table T[q][id] = (q.E[id] + bias[id]) * tscale  (log2 domain) ---
+  // prefetch of the first tile overlaps the table construction
+  Frag<T> kf;
+  VTile<T> vt;
+  {
+    const int k0 = tile_at(0) * 32;
+    kf.load_row(K + (unsigned)min(k0 + r, p.S - 1) * ks1, h);
+    vt.load(V, vs1, k0, p.S, lane, 0);
+  }
+
+  // ---- relative-score table T[q][col(id)] = (q.E[id] + bias[id]) * tscale  (log2 domain) --
+  const int id_mode = p.pat.id_mode, mdist = p.pat.m;
   if (p.R > 0) {
     const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
 #pragma unroll
     for (int rb = 0; rb < Rp / 32; ++rb) {
       const int rr = rb * 32 + r;
       Frag<T> ef;
-      ef.load_row(E + (long)(rr < p.R ? rr : 0) * p.N * 64, h, rr < p.R);
+      ef.load_row(E + (long)min(rr, p.R - 1) * p.N * 64, h);   // columns >= R are never read
       f32x16 c = {0};
       c = mma_rows(ef, qf, c);  // [id x q]
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int id = rb * 32 + kap(i, h);
         float bias = 0.f;
-        if (p.bias && id < p.R) bias = (float)reinterpret_cast<const T*>(p.bias)[(long)id * p.N + n];
-        tab[r * kTStride(Rp) + id] = (c[i] + bias) * p.tscale;
+        if (p.bias) bias = (float)reinterpret_cast<const T*>(p.bias)[(long)min(id, p.R - 1) * p.N + n];
+        const int col = (MODE == kDense || GEN) ? id : tcol(p.perm_1d, mdist, id);
+        tab[r * kTStride(Rp) + col] = (c[i] + bias) * p.tscale;
       }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
-  // ---- tile walk -----------------------------------------------------------------------
   f32x16 o0 = {0}, o1 = {0};
   float m_run = -INFINITY, l_run = 0.f;
-  const int n_tiles = (p.S + 31) >> 5;
-  int t_lo, t_hi, g_lo = 0, g_hi = -1;
-  if (MODE == kBand) {
-    const int lo = q0 - p.pat.radius, hi = q0 + 31 + p.pat.radius;
-    t_lo = (lo < 0 ? 0 : lo) >> 5;
-    t_hi = (hi >= p.S || hi < 0 /*overflow*/ ? p.S - 1 : hi) >> 5;
-    if (p.pat.ng > 0) { g_lo = p.pat.g0 >> 5; g_hi = (p.pat.g0 + p.pat.ng - 1) >> 5; }
-  } else if (MODE == kRows) {
-    t_lo = chunk * p.chunk_tiles;
-    t_hi = min(n_tiles, t_lo + p.chunk_tiles) - 1;
-  } else {
-    t_lo = 0; t_hi = n_tiles - 1;
-  }
-  const int n_band = t_hi - t_lo + 1;
-  const int n_glob = g_hi - g_lo + 1;
+  const float* trow = tab + r * kTStride(Rp);
+  // whole q-block on one side of valid_len?  (needed for the fast path)
+  const bool qblk_valid = q0 + 31 < valid_len, qblk_pad = q0 >= valid_len;
+  const bool qblk_plain = q0 + 31 < p.S && !(p.pat.ng > 0 && q0 + 31 >= p.pat.g0 && q0 < p.pat.g0 + p.pat.ng);
 
-  for (int it = 0; it < n_band + n_glob; ++it) {
-    int t;
-    if (it < n_band) t = t_lo + it;
-    else { t = g_lo + (it - n_band); if (t >= t_lo && t <= t_hi) continue; }
-    const int k0 = t * 32;
+  for (int it = 0; it < n_it; ++it) {
+    const int k0 = tile_at(it) * 32;
+    vt.to_lds(vlds, lane);
 
-    // K fragment of key (k0 + r) and S^T = K.Q^T
-    Frag<T> kf;
-    {
-      const int kk = k0 + r;
-      kf.load_row(K + (long)(kk < p.S ? kk : 0) * p.ks[1], h, kk < p.S);
-    }
-    // V tile -> wave-private LDS (bf16) while the QK^T MFMAs run
-    if constexpr (sizeof(T) == 2) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int ci = lane + 64 * u, row = ci >> 3, ch = ci & 7;
-        const int kk = k0 + row;
-        bf16x8 t8 = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (kk < p.S) t8 = *reinterpret_cast<const bf16x8*>(V + (long)kk * p.vs[1] + ch * 8);
-        const int off = row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
-        *reinterpret_cast<bf16x8*>(vlds + off) = t8;
-      }
-    }
     f32x16 c = {0};
     c = mma_rows(kf, qf, c);
 
-    // scores in the log2 domain: s2 = (qk [+ rel]) * scale*log2e [+ rel'] + mask_add
+    VTile<T> vcur;
+    if constexpr (sizeof(T) == 4) vcur = vt;
+    if (it + 1 < n_it) {   // prefetch the next tile (registers) under this tile's math
+      const int k1 = tile_at(it + 1) * 32;
+      kf.load_row(K + (unsigned)min(k1 + r, p.S - 1) * ks1, h);
+      vt.load(V, vs1, k1, p.S, lane, 0);
+    }
+
+    // ---- scores in the log2 domain --------------------------------------------------------
     float s2[16];
     float tmax = -INFINITY;
+    bool fast = false;
+    if (MODE == kBand) {
+      // wave-uniform classification: every (q,k) of the tile unmasked and 1-D (or no) ids
+      const bool seg_all = (qblk_valid && k0 + 31 < valid_len) || (qblk_pad && k0 >= valid_len);
+      const bool band_all = (k0 - (q0 + 31) >= -p.pat.radius) && (k0 + 31 - q0 <= p.pat.radius);
+      fast = !GEN && seg_all && band_all && qblk_plain && k0 + 31 < p.S;
+    }
+    constexpr bool cheap_ids = MODE == kBand && !GEN;
+    if (!GEN && fast) {
+      const int d0 = k0 - q + 4 * h;
+      if (id_mode == 1) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int kk = k0 + kap(i, h);
-      bool keep;
-      int id = -1;
-      if (MODE == kDense) {
-        const long off = ((long)b * p.S + (q_ok ? q : 0)) * p.S + (kk < p.S ? kk : 0);
-        keep = p.att_mask ? p.att_mask[off] != 0 : true;
-        if (p.rel_ids) id = p.rel_ids[off];
+        for (int i = 0; i < 16; ++i) {
+          const int d = d0 + (i & 3) + 8 * (i >> 2);
+          const int col = min(max(d, -mdist), mdist) + mdist;  // < R: perm_1d implies R >= 2m+1
+          s2[i] = fmaf(c[i], p.sscale, trow[col]);
+          tmax = fmaxf(tmax, s2[i]);
+        }
       } else {
-        keep = pattern_mask(p.pat, valid_len, q, kk);
-        if (p.pat.id_mode) id = rel_id(p.pat, q, kk);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s2[i] = c[i] * p.sscale; tmax = fmaxf(tmax, s2[i]); }
       }
-      float rel = 0.f;
-      if ((unsigned)id < (unsigned)p.R) rel = tab[r * kTStride(Rp) + id];
-      float s = fmaf(c[i], p.sscale, rel);
-      if (!keep) s += p.mask_add;
-      if (kk >= p.S) s = -INFINITY;
-      s2[i] = s;
-      tmax = fmaxf(tmax, s);
+    } else if constexpr (cheap_ids) {
+      // branch-free pattern mask, 1-D (permuted table) or no ids
+      const int kb = k0 + 4 * h, d0 = kb - q;
+      const unsigned W = (unsigned)p.pat.radius;
+      const bool qv = q < valid_len, gq = is_global(p.pat, q);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2);
+        const int kk = kb + ci, d = d0 + ci;
+        const bool near = (unsigned)(d + (int)W) <= 2u * W;
+        const bool gk = (unsigned)(kk - p.pat.g0) < (unsigned)p.pat.ng;
+        const bool seg = (kk < valid_len) == qv;
+        const bool keep = seg & (near | gk | gq);
+        float rel = 0.f;
+        if (id_mode == 1) rel = trow[min(max(d, -mdist), mdist) + mdist];
+        float s = fmaf(c[i], p.sscale, rel);
+        s = keep ? s : s + p.mask_add;
+        s = kk < p.S ? s : -INFINITY;
+        s2[i] = s;
+        tmax = fmaxf(tmax, s);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kk = k0 + kap(i, h);
+        bool keep;
+        int id = -1;
+        if (MODE == kDense) {
+          const long off = ((long)b * p.S + (q_ok ? q : 0)) * p.S + (kk < p.S ? kk : 0);
+          keep = p.att_mask ? p.att_mask[off] != 0 : true;
+          if (p.rel_ids) id = p.rel_ids[off];
+        } else {
+          keep = pattern_mask(p.pat, valid_len, q, kk);
+          if (id_mode) id = rel_id(p.pat, q, kk);
+        }
+        float rel = 0.f;
+        if ((unsigned)id < (unsigned)p.R) rel = trow[id];
+        float s = fmaf(c[i], p.sscale, rel);
+        if (!keep) s += p.mask_add;
+        if (kk >= p.S) s = -INFINITY;
+        s2[i] = s;
+        tmax = fmaxf(tmax, s);
+      }
     }
     tmax = fmaxf(tmax, half_xchg(tmax));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
+    // Deferred rescale: the running reference m_run only moves when some row's tile maximum
+    // exceeds it by more than kRescaleThr (log2 units), so p stays <= 2^kRescaleThr; O, l and
+    // p always share one reference, hence the normalised result is unchanged.
+    if (__any(tmax > m_run + kRescaleThr)) {
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+    }
     float psum = 0.f;
     float pr[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      pr[i] = exp2f(s2[i] - m_new);
+      pr[i] = __builtin_amdgcn_exp2f(s2[i] - m_run);
       psum += pr[i];
     }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+    l_run += psum;
 
     if (p.drop_thresh) {
 #pragma unroll
@@ -231,10 +338,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
       }
     }
 
-    // O^T[d x q] += V^T[d x key] . P^T[key x q]
+    // ---- O^T[d x q] += V^T[d x key] . P^T[key x q] -------------------------------------------
     if constexpr (sizeof(T) == 2) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
       const int li = lane & 15, cb = (lane >> 4) & 1;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -260,26 +365,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
           else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o1, 0, 0, 0);
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll
       for (int s = 0; s < 16; ++s) {
-        const int kk = k0 + kap(s, h);
-        float v0 = 0.f, v1 = 0.f;
-        if (kk < p.S) {
-          const float* vr = reinterpret_cast<const float*>(V) + (long)kk * p.vs[1];
-          v0 = vr[r]; v1 = vr[32 + r];
-        }
-        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, pr[s], o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, pr[s], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur.a0[s], pr[s], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vcur.a1[s], pr[s], o1, 0, 0, 0);
       }
     }
   }
 
   // ---- epilogue --------------------------------------------------------------------------
   const float l_tot = l_run + half_xchg(l_run);
-  if (MODE == kRows) {
+  if (rows_item) {
     // partial, unnormalised: part_o[bn][rowblk][chunk][q 32][d 64], part_ml[...][2][32]
     const long slot = ((long)bn * p.n_rowblk + rowblk) * p.n_chunks + chunk;
     float* po = p.part_o + slot * (32 * 64) + r * 64;
@@ -315,7 +412,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
   if (p.lse && h == 0) p.lse[((long)b * p.N + n) * p.S + q] = (m_run + log2f(l_tot)) * kLn2;
 }
 
-// Combine the per-chunk partials of the global rows: one thread per (row, d).
+// Combine the per-chunk partials of the global rows: one wave per (row, bn), lane = d.
 template <typename T>
 __global__ __launch_bounds__(64) void attn_rows_combine_kernel(const FwdParams p) {
   const int bn = blockIdx.y;
@@ -339,33 +436,31 @@ __global__ __launch_bounds__(64) void attn_rows_combine_kernel(const FwdParams p
 }
 
 // ------------------------------------ launchers -----------------------------------------
-template <typename T, int MODE, int Rp>
+template <typename T, int MODE, int Rp, bool GEN>
 static hipError_t launch_one(const FwdParams& p, dim3 grid, hipStream_t st) {
   const int lds = 4 * WaveLds<T, Rp>::kBytes;
-  hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, Rp>), grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, Rp, GEN>), grid, dim3(256), lds, st, p);
   return hipGetLastError();
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool GEN>
 static hipError_t launch_rp(const FwdParams& p, dim3 grid, hipStream_t st) {
-  if (p.R <= 32) return launch_one<T, MODE, 32>(p, grid, st);
-  return launch_one<T, MODE, 64>(p, grid, st);
+  if (p.R <= 32) return launch_one<T, MODE, 32, GEN>(p, grid, st);
+  return launch_one<T, MODE, 64, GEN>(p, grid, st);
 }
 
 template <typename T>
-static hipError_t launch_mode(const FwdParams& p, int mode, dim3 grid, hipStream_t st) {
-  switch (mode) {
-    case kBand: return launch_rp<T, kBand>(p, grid, st);
-    case kDense: return launch_rp<T, kDense>(p, grid, st);
-    default: return launch_rp<T, kRows>(p, grid, st);
-  }
+static hipError_t launch_t(const FwdParams& p, int mode, dim3 grid, hipStream_t st) {
+  if (mode == kDense) return launch_rp<T, kDense, true>(p, grid, st);
+  const bool gen = !(p.pat.id_mode == 0 || p.perm_1d);
+  return gen ? launch_rp<T, kBand, true>(p, grid, st) : launch_rp<T, kBand, false>(p, grid, st);
 }
 
 hipError_t launch_attn_fwd(const FwdParams& p, int mode, bool bf16, hipStream_t st) {
-  dim3 grid;
-  if (mode == kRows) grid = dim3((p.n_chunks * p.n_rowblk + 3) / 4, p.B * p.N);
-  else grid = dim3(p.B * p.N * ((p.S + 127) / 128));
-  return bf16 ? launch_mode<__bf16>(p, mode, grid, st) : launch_mode<float>(p, mode, grid, st);
+  // band items first, then (kBand only) the global-row items of the same launch
+  const int per_bn = (p.n_chunks * p.n_rowblk + 3) / 4;
+  dim3 grid(p.n_band_blocks + (mode == kBand ? per_bn * p.B * p.N : 0));
+  return bf16 ? launch_t<__bf16>(p, mode, grid, st) : launch_t<float>(p, mode, grid, st);
 }
 
 hipError_t launch_rows_combine(const FwdParams& p, bool bf16, hipStream_t st) {

@@ -28,6 +28,8 @@ struct FwdParams {
   float* part_o;
   float* part_ml;
   int n_chunks, chunk_tiles, n_rowblk;
+  int n_band_blocks;  // B*N*ceil(S/128): blocks before the global-row items
+  int perm_1d;        // 1-D ids with R >= 2m+1: table columns permuted, fast path allowed
 };
 
 hipError_t launch_attn_fwd(const FwdParams& p, int mode, bool bf16, hipStream_t st);

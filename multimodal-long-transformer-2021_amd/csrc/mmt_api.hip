@@ -43,6 +43,8 @@ int check_desc(const mmt_attn_desc* d) {
   for (int t = 0; t < 4; ++t)
     for (int i = 0; i < 3; ++i)
       if (st[t][i] < 0 || st[t][i] % align) return fail(MMT_E_INVALID, "strides must be non-negative multiples of %d elements", align);
+  for (int t = 0; t < 4; ++t)
+    if ((int64_t)d->S * st[t][1] >= (int64_t)1 << 31) return fail(MMT_E_UNSUPPORTED, "S * stride_s must stay below 2^31 elements");
   if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return fail(MMT_E_INVALID, "dropout_p must be in [0,1)");
   const mmt_mask_desc& m = d->mask;
   if (m.local_radius < 0) return fail(MMT_E_INVALID, "local_radius must be >= 0");
@@ -136,6 +138,8 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   p.q = q; p.k = k; p.v = v; p.emb = rel_emb; p.bias = rel_bias; p.out = out; p.lse = lse;
   p.att_mask = att_mask; p.rel_ids = rel_ids;
   if (desc->R == 0) { p.pat.id_mode = 0; p.rel_ids = nullptr; }
+  p.n_band_blocks = desc->B * desc->N * ((desc->S + 127) / 128);
+  p.perm_1d = (!dense && p.pat.id_mode == MMT_IDS_1D && desc->R >= 2 * p.pat.m + 1) ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const bool bf16 = desc->dtype == MMT_BF16;
 
@@ -146,14 +150,14 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     return MMT_OK;
   }
   p.skip_global_rows = pl.split_rows ? 1 : 0;
-  e = mmt::launch_attn_fwd(p, mmt::kBand, bf16, st);
-  if (e != hipSuccess) return fail(MMT_E_LAUNCH, "band forward launch: %s", hipGetErrorString(e));
   if (pl.split_rows) {
     p.n_rowblk = pl.n_rowblk; p.n_chunks = pl.n_chunks; p.chunk_tiles = kChunkTiles;
     p.part_o = reinterpret_cast<float*>(workspace);
     p.part_ml = p.part_o + (size_t)desc->B * desc->N * pl.n_rowblk * pl.n_chunks * (32 * 64);
-    e = mmt::launch_attn_fwd(p, mmt::kRows, bf16, st);
-    if (e != hipSuccess) return fail(MMT_E_LAUNCH, "global-rows forward launch: %s", hipGetErrorString(e));
+  }
+  e = mmt::launch_attn_fwd(p, mmt::kBand, bf16, st);
+  if (e != hipSuccess) return fail(MMT_E_LAUNCH, "band forward launch: %s", hipGetErrorString(e));
+  if (pl.split_rows) {
     e = mmt::launch_rows_combine(p, bf16, st);
     if (e != hipSuccess) return fail(MMT_E_LAUNCH, "global-rows combine launch: %s", hipGetErrorString(e));
   }
