@@ -1,0 +1,575 @@
+// Backward of QkvRelativeAttention for gfx950 (MI355X).  Math: SURVEY.md App. A.3
+// differentiated (checked against oracle/attention.py::relative_attention_bwd):
+//
+//   P = softmax(s),  s = (q.k + relall[q,id]) * scale + maskadd,  O = drop(P) V
+//   dV = drop(P)^T dO;  dP = drop'(dO V^T);  dS = P o (dP - delta),  delta = rowsum(dO o O)
+//   dQ = gscale * dS K + dRel E;   dK = gscale * dS^T Q
+//   dRel[q,r] = rel_gscale * sum_k dS[q,k] [id(q,k) = r];  dE = dRel^T Q;  dbias = colsum(dRel)
+//
+// Two deterministic, atomic-free passes that recompute P from the forward's LSE:
+//   attn_bwd_dq_kernel  : one wave = 32 query rows (row on the lane, as the forward);
+//                         walks key tiles; produces dQ, delta, dRel.                     [K4a]
+//   attn_bwd_dkv_kernel : one wave = 32 keys (key on the lane, query rows in registers);
+//                         walks query tiles; produces dK, dV.                            [K4b]
+// Global rows (K4a) / global keys (K4b) see the whole sequence: they are split into chunks
+// handled by extra work items of the same launch, summed by small combine kernels.
+// dE / dbias: two-stage tree reduction of dRel^T Q (no atomics, bitwise reproducible).
+#include "attn_tile.h"
+
+namespace mmt {
+
+// LDS per wave: T table, dT table (K4a) / second tile (K4b), one or two 32 x 128 B tiles.
+template <typename T, int Rp> struct BwdLds {
+  static constexpr int kTab = (32 * kTStride(Rp) * 4 + 15) & ~15;
+  static constexpr int kTile = sizeof(T) == 2 ? 32 * 128 : 0;
+  static constexpr int kDq = 2 * kTab + kTile;        // tab, dtab, K/E tile
+  static constexpr int kDkv = kTab + 2 * kTile;       // tab, Q tile, dO tile
+};
+
+struct TileWalk {
+  int a0, lenA, b0, lenB, c0, lenC;
+  __device__ __forceinline__ int count() const { return lenA + lenB + lenC; }
+  __device__ __forceinline__ int at(int it) const {
+    return it < lenA ? a0 + it : (it < lenA + lenB ? b0 + (it - lenA) : c0 + (it - lenA - lenB));
+  }
+};
+
+// Tiles a 32-row block starting at x0 must visit: the band around it plus the tiles that hold
+// global tokens (the pattern is symmetric in (q,k), so this serves both passes).
+__device__ __forceinline__ TileWalk band_walk(const PatternDev& pat, int x0, int S) {
+  TileWalk w{0, 0, 0, 0, 0, 0};
+  const int lo = max(x0 - pat.radius, 0), hi = min(x0 + 31 + pat.radius, S - 1);
+  w.b0 = lo >> 5;
+  const int b1 = hi >> 5;
+  w.lenB = b1 - w.b0 + 1;
+  if (pat.ng > 0) {
+    const int g_lo = pat.g0 >> 5, g_hi = (pat.g0 + pat.ng - 1) >> 5;
+    w.a0 = g_lo; w.lenA = max(0, min(g_hi, w.b0 - 1) - g_lo + 1);
+    w.c0 = max(g_lo, b1 + 1); w.lenC = max(0, g_hi - w.c0 + 1);
+  }
+  return w;
+}
+
+// Score of one (q,k) pair in the log2 domain + the table column of its relative id.
+// Returns false when the pair does not exist (q or k past the end).
+template <int MODE, bool GEN, typename P>
+__device__ __forceinline__ bool pair_score(const P& p, int b, int valid_len, int q, int k, float dot,
+                                           const float* trow, float& s2, int& col) {
+  bool keep;
+  int id = -1;
+  col = -1;
+  if (MODE == kDense) {
+    const long off = ((long)b * p.S + min(q, p.S - 1)) * p.S + min(k, p.S - 1);
+    keep = p.att_mask ? p.att_mask[off] != 0 : true;
+    if (p.rel_ids) id = p.rel_ids[off];
+    if ((unsigned)id < (unsigned)p.R) col = id;
+  } else if (GEN) {
+    keep = pattern_mask(p.pat, valid_len, q, k);
+    if (p.pat.id_mode) id = rel_id(p.pat, q, k);
+    if ((unsigned)id < (unsigned)p.R) col = id;
+  } else {
+    const int d = k - q;
+    const unsigned W = (unsigned)p.pat.radius;
+    const bool near = (unsigned)(d + (int)W) <= 2u * W;
+    const bool seg = (k < valid_len) == (q < valid_len);
+    keep = (int)seg & ((int)near | (int)is_global(p.pat, k) | (int)is_global(p.pat, q));
+    if (p.pat.id_mode == 1) col = min(max(d, -p.pat.m), p.pat.m) + p.pat.m;
+  }
+  const float rel = col >= 0 ? trow[col] : 0.f;
+  float s = fmaf(dot, p.sscale, rel);
+  s = keep ? s : s + p.mask_add;
+  s2 = s;
+  return (q < p.S) && (k < p.S);
+}
+
+template <typename T, typename P>
+__device__ __forceinline__ float drop_factor(const P& p, int bn, int q, int k) {
+  if (!p.drop_thresh) return 1.f;
+  const uint32_t hsh = dropout_hash(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q, (uint32_t)k);
+  return hsh >= p.drop_thresh ? p.inv_keep : 0.f;
+}
+
+// Builds T[row][col(id)] = (x_row . E[id] + bias[id]) * tscale for the 32 rows whose fragments
+// are in `xf` (row = lane & 31).
+template <typename T, int Rp, bool IDENT, typename P>
+__device__ __forceinline__ void build_table(const P& p, int n, const Frag<T>& xf, float* tab, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
+#pragma unroll
+  for (int rb = 0; rb < Rp / 32; ++rb) {
+    const int rr = rb * 32 + r;
+    Frag<T> ef;
+    ef.load_row(E + (long)min(rr, p.R - 1) * p.N * 64, h);
+    f32x16 c = {0};
+    c = mma_rows(ef, xf, c);  // [id x row]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int id = rb * 32 + kap(i, h);
+      float bias = 0.f;
+      if (p.bias) bias = (float)reinterpret_cast<const T*>(p.bias)[(long)min(id, p.R - 1) * p.N + n];
+      const int col = IDENT ? id : tcol(p.perm_1d, p.pat.m, id);
+      tab[r * kTStride(Rp) + col] = (c[i] + bias) * p.tscale;
+    }
+  }
+}
+
+// =========================================================================================
+// K4a: dQ, delta, dRel.  Lane (r,h) owns query row q0 + r; registers walk keys.
+// =========================================================================================
+template <typename T, int MODE, int Rp, bool GEN>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  using L = BwdLds<T, Rp>;
+  unsigned char* wl = smem + wave * L::kDq;
+  float* tab = reinterpret_cast<float*>(wl);
+  float* dtab = reinterpret_cast<float*>(wl + L::kTab);
+  unsigned char* xlds = wl + 2 * L::kTab;
+  constexpr bool IDENT = MODE == kDense || GEN;
+
+  const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
+  const bool split_item = MODE == kBand && (int)blockIdx.x >= p.n_band_blocks;
+  int bn, q0, chunk = 0, gblk = 0;
+  if (split_item) {
+    const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
+    const int rb = blockIdx.x - p.n_band_blocks;
+    bn = rb / per_bn;
+    const int item = (rb - bn * per_bn) * 4 + wave;
+    if (item >= p.n_chunks * p.n_gblk) return;
+    gblk = item / p.n_chunks;
+    chunk = item - gblk * p.n_chunks;
+    q0 = p.pat.g0 + gblk * 32;
+  } else {
+    const int wg = xcd_remap(blockIdx.x, p.n_band_blocks);
+    bn = wg / nqb;
+    q0 = (wg - bn * nqb) * 128 + wave * 32;
+    if (q0 >= p.S) return;
+  }
+  const int b = bn / p.N, n = bn - b * p.N;
+  const int q = q0 + r;
+  const bool q_ok = q < p.S;
+  const unsigned qc = (unsigned)min(q, p.S - 1);
+  const int valid_len = p.valid_len ? p.valid_len[b] : p.S;
+  const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)n * p.qs[2];
+  const T* K = reinterpret_cast<const T*>(p.k) + (long)b * p.ks[0] + (long)n * p.ks[2];
+  const T* V = reinterpret_cast<const T*>(p.v) + (long)b * p.vs[0] + (long)n * p.vs[2];
+  const T* O = reinterpret_cast<const T*>(p.out) + (long)b * p.os[0] + (long)n * p.os[2];
+  const T* DO = reinterpret_cast<const T*>(p.dout) + (long)b * p.os[0] + (long)n * p.os[2];
+  const unsigned qs1 = (unsigned)p.qs[1], ks1 = (unsigned)p.ks[1], vs1 = (unsigned)p.vs[1], os1 = (unsigned)p.os[1];
+
+  TileWalk w{0, 0, 0, n_tiles, 0, 0};
+  if (MODE == kBand) {
+    if (split_item) { w.b0 = chunk * p.chunk_tiles; w.lenB = min(n_tiles, w.b0 + p.chunk_tiles) - w.b0; }
+    else w = band_walk(p.pat, q0, p.S);
+  }
+
+  Frag<T> qf, dof;
+  qf.load_row(Q + qc * qs1, h);
+  dof.load_row(DO + qc * os1, h);
+  float delta;
+  {
+    Frag<T> of;
+    of.load_row(O + qc * os1, h);
+    float acc = 0.f;
+    constexpr int kN = sizeof(T) == 2 ? 4 : 32;
+#pragma unroll
+    for (int s = 0; s < kN; ++s) {
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = fmaf((float)of.v[s][j], (float)dof.v[s][j], acc);
+      } else {
+        acc = fmaf(of.v[s], dof.v[s], acc);
+      }
+    }
+    delta = acc + half_xchg(acc);
+  }
+  const long row_id = ((long)b * p.N + n) * p.S + qc;
+  if (!split_item && q_ok && h == 0) p.delta[row_id] = delta;
+  const float lse2 = p.lse[row_id] * kLog2e;
+
+  if (p.R > 0) build_table<T, Rp, IDENT>(p, n, qf, tab, lane);
+  for (int i = lane; i < 32 * kTStride(Rp); i += 64) dtab[i] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  f32x16 a0 = {0}, a1 = {0};
+  const float* trow = tab + r * kTStride(Rp);
+  float* dtrow = dtab + r * kTStride(Rp);
+  const int n_it = w.count();
+  for (int it = 0; it < n_it; ++it) {
+    const int k0 = w.at(it) * 32;
+    Frag<T> kf, vf;
+    kf.load_row(K + (unsigned)min(k0 + r, p.S - 1) * ks1, h);
+    vf.load_row(V + (unsigned)min(k0 + r, p.S - 1) * vs1, h);
+    VTile<T> kt;
+    kt.load(K, ks1, k0, p.S, lane, 0);
+    kt.to_lds(xlds, lane);
+    f32x16 c = {0}, dp = {0};
+    c = mma_rows(kf, qf, c);     // S^T  [key x q]
+    dp = mma_rows(vf, dof, dp);  // dP^T [key x q]
+    float g[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kk = k0 + kap(i, h);
+      float s2; int col;
+      const bool exists = pair_score<MODE, GEN>(p, b, valid_len, q, kk, c[i], trow, s2, col);
+      const float pr = exists ? __builtin_amdgcn_exp2f(s2 - lse2) : 0.f;
+      const float ds = pr * (dp[i] * drop_factor<T>(p, bn, q, kk) - delta);
+      g[i] = ds * p.gscale;
+      if (col >= 0) atomicAdd(&dtrow[col], ds * p.rel_gscale);
+    }
+    mma_xt(a0, a1, kt, xlds, g, lane);   // dQ^T[d x q] += K^T[d x key] . dS^T[key x q]
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+
+  if (split_item) {
+    const long slot = ((long)bn * p.n_gblk + gblk) * p.n_chunks + chunk;
+    float* po = p.part_dq + slot * (32 * 64) + r * 64;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      *reinterpret_cast<f32x4*>(po + 8 * gi + 4 * h) = f32x4{a0[4 * gi], a0[4 * gi + 1], a0[4 * gi + 2], a0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(po + 32 + 8 * gi + 4 * h) = f32x4{a1[4 * gi], a1[4 * gi + 1], a1[4 * gi + 2], a1[4 * gi + 3]};
+    }
+    float* pt = p.part_dtab + slot * (32 * Rp);
+    for (int i = lane; i < 32 * Rp; i += 64) {
+      const int rr = i / Rp, id = i - rr * Rp;
+      pt[i] = dtab[rr * kTStride(Rp) + (IDENT ? id : tcol(p.perm_1d, p.pat.m, id))];
+    }
+    return;
+  }
+
+  // dQ^T += E^T[d x id] . dRel^T[id x q]   (dRel kept at ~16 mantissa bits: hi/lo bf16 split)
+  if (p.R > 0) {
+    const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
+    float* dr = p.drel + row_id * Rp;
+#pragma unroll
+    for (int rb = 0; rb < Rp / 32; ++rb) {
+      float vals[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int id = rb * 32 + kap(i, h);
+        vals[i] = id < p.R ? dtrow[IDENT ? id : tcol(p.perm_1d, p.pat.m, id)] : 0.f;
+      }
+      if (q_ok && !(p.skip_global && is_global(p.pat, q))) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi)
+          *reinterpret_cast<f32x4*>(dr + rb * 32 + 8 * gi + 4 * h) = f32x4{vals[4 * gi], vals[4 * gi + 1], vals[4 * gi + 2], vals[4 * gi + 3]};
+      }
+      VTile<T> et;   // rows = ids rb*32 .. rb*32+31 of E (clamped past R: their dRel is 0)
+      et.load(E + (long)(rb * 32) * p.N * 64, (unsigned)(p.N * 64), 0, max(p.R - rb * 32, 1), lane, 0);
+      et.to_lds(xlds, lane);
+      mma_xt_hilo(a0, a1, et, xlds, vals, lane);
+    }
+  }
+  if (!q_ok || (p.skip_global && is_global(p.pat, q))) return;
+  T* DQ = reinterpret_cast<T*>(p.dq) + (long)b * p.qs[0] + (long)q * p.qs[1] + (long)n * p.qs[2];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const int d = 8 * gi + 4 * h;
+    if constexpr (sizeof(T) == 2) {
+      bf16x4 x, y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x[j] = (__bf16)a0[4 * gi + j]; y[j] = (__bf16)a1[4 * gi + j]; }
+      *reinterpret_cast<bf16x4*>(DQ + d) = x;
+      *reinterpret_cast<bf16x4*>(DQ + 32 + d) = y;
+    } else {
+      *reinterpret_cast<f32x4*>(DQ + d) = f32x4{a0[4 * gi], a0[4 * gi + 1], a0[4 * gi + 2], a0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(DQ + 32 + d) = f32x4{a1[4 * gi], a1[4 * gi + 1], a1[4 * gi + 2], a1[4 * gi + 3]};
+    }
+  }
+}
+
+// Global rows: sum the chunk partials, add dRel.E, write dQ / dRel / nothing else.
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_dq_combine_kernel(const BwdParams p) {
+  const int bn = blockIdx.y, row = blockIdx.x, d = threadIdx.x;
+  const int gblk = row >> 5, rr = row & 31;
+  const int b = bn / p.N, n = bn - b * p.N;
+  const int q = p.pat.g0 + row;
+  const long slot0 = ((long)bn * p.n_gblk + gblk) * p.n_chunks;
+  float acc = 0.f;
+  for (int c = 0; c < p.n_chunks; ++c) acc += p.part_dq[(slot0 + c) * (32 * 64) + rr * 64 + d];
+  const long row_id = ((long)b * p.N + n) * p.S + q;
+  const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
+  for (int id = 0; id < p.R; ++id) {
+    float dr = 0.f;
+    for (int c = 0; c < p.n_chunks; ++c) dr += p.part_dtab[(slot0 + c) * (32 * p.Rp) + rr * p.Rp + id];
+    acc = fmaf(dr, (float)E[(long)id * p.N * 64 + d], acc);
+    if (d == 0) p.drel[row_id * p.Rp + id] = dr;
+  }
+  if (d == 0) for (int id = p.R; id < p.Rp; ++id) p.drel[row_id * p.Rp + id] = 0.f;
+  T* DQ = reinterpret_cast<T*>(p.dq) + (long)b * p.qs[0] + (long)q * p.qs[1] + (long)n * p.qs[2];
+  DQ[d] = (T)acc;
+}
+
+// =========================================================================================
+// K4b: dK, dV.  Lane (r,h) owns key k0 + r; registers walk query rows.
+// =========================================================================================
+template <typename T, int MODE, int Rp, bool GEN>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  using L = BwdLds<T, Rp>;
+  unsigned char* wl = smem + wave * L::kDkv;
+  float* tab = reinterpret_cast<float*>(wl);
+  unsigned char* qlds = wl + L::kTab;
+  unsigned char* dolds = qlds + L::kTile;
+  constexpr bool IDENT = MODE == kDense || GEN;
+
+  const int n_tiles = (p.S + 31) >> 5, nkb = (p.S + 127) >> 7;
+  const bool split_item = MODE == kBand && (int)blockIdx.x >= p.n_band_blocks;
+  int bn, k0, chunk = 0, gblk = 0;
+  if (split_item) {
+    const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
+    const int rb = blockIdx.x - p.n_band_blocks;
+    bn = rb / per_bn;
+    const int item = (rb - bn * per_bn) * 4 + wave;
+    if (item >= p.n_chunks * p.n_gblk) return;
+    gblk = item / p.n_chunks;
+    chunk = item - gblk * p.n_chunks;
+    k0 = p.pat.g0 + gblk * 32;
+  } else {
+    const int wg = xcd_remap(blockIdx.x, p.n_band_blocks);
+    bn = wg / nkb;
+    k0 = (wg - bn * nkb) * 128 + wave * 32;
+    if (k0 >= p.S) return;
+  }
+  const int b = bn / p.N, n = bn - b * p.N;
+  const int k = k0 + r;
+  const bool k_ok = k < p.S;
+  const unsigned kc = (unsigned)min(k, p.S - 1);
+  const int valid_len = p.valid_len ? p.valid_len[b] : p.S;
+  const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)n * p.qs[2];
+  const T* K = reinterpret_cast<const T*>(p.k) + (long)b * p.ks[0] + (long)n * p.ks[2];
+  const T* V = reinterpret_cast<const T*>(p.v) + (long)b * p.vs[0] + (long)n * p.vs[2];
+  const T* DO = reinterpret_cast<const T*>(p.dout) + (long)b * p.os[0] + (long)n * p.os[2];
+  const unsigned qs1 = (unsigned)p.qs[1], ks1 = (unsigned)p.ks[1], vs1 = (unsigned)p.vs[1], os1 = (unsigned)p.os[1];
+  const float* lse_bn = p.lse + ((long)b * p.N + n) * p.S;
+  const float* delta_bn = p.delta + ((long)b * p.N + n) * p.S;
+
+  TileWalk w{0, 0, 0, n_tiles, 0, 0};
+  if (MODE == kBand) {
+    if (split_item) { w.b0 = chunk * p.chunk_tiles; w.lenB = min(n_tiles, w.b0 + p.chunk_tiles) - w.b0; }
+    else w = band_walk(p.pat, k0, p.S);
+  }
+
+  Frag<T> kf, vf;
+  kf.load_row(K + kc * ks1, h);
+  vf.load_row(V + kc * vs1, h);
+  f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  const int n_it = w.count();
+  for (int it = 0; it < n_it; ++it) {
+    const int q0 = w.at(it) * 32;
+    Frag<T> qf, dof;
+    qf.load_row(Q + (unsigned)min(q0 + r, p.S - 1) * qs1, h);
+    dof.load_row(DO + (unsigned)min(q0 + r, p.S - 1) * os1, h);
+    VTile<T> qt, dot;
+    qt.load(Q, qs1, q0, p.S, lane, 0);
+    dot.load(DO, os1, q0, p.S, lane, 0);
+    qt.to_lds(qlds, lane);
+    dot.to_lds(dolds, lane);
+    if (p.R > 0) build_table<T, Rp, IDENT>(p, n, qf, tab, lane);   // T rows = this q tile
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x16 c = {0}, dp = {0};
+    c = mma_rows(qf, kf, c);     // S  [q x key]
+    dp = mma_rows(dof, vf, dp);  // dP [q x key]
+    float pv[16], g[16];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const int qb = q0 + 8 * gi + 4 * h;      // 4 consecutive query rows
+      float l4[4], d4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int qq = min(qb + j, p.S - 1);
+        l4[j] = lse_bn[qq] * kLog2e;
+        d4[j] = delta_bn[qq];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = 4 * gi + j, qq = qb + j;
+        float s2; int col;
+        const bool exists = pair_score<MODE, GEN>(p, b, valid_len, qq, k, c[i],
+                                                   tab + (8 * gi + 4 * h + j) * kTStride(Rp), s2, col);
+        const float pr = exists ? __builtin_amdgcn_exp2f(s2 - l4[j]) : 0.f;
+        const float df = drop_factor<T>(p, bn, qq, k);
+        pv[i] = pr * df;
+        g[i] = pr * (dp[i] * df - d4[j]) * p.gscale;
+      }
+    }
+    mma_xt(dv0, dv1, dot, dolds, pv, lane);  // dV^T[d x key] += dO^T[d x q] . P[q x key]
+    mma_xt(dk0, dk1, qt, qlds, g, lane);     // dK^T[d x key] += Q^T[d x q] . dS[q x key]
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  if (split_item) {
+    const long slot = ((long)bn * p.n_gblk + gblk) * p.n_chunks + chunk;
+    float* pk = p.part_dkv + slot * (2 * 32 * 64) + r * 64;
+    float* pv2 = pk + 32 * 64;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      *reinterpret_cast<f32x4*>(pk + 8 * gi + 4 * h) = f32x4{dk0[4 * gi], dk0[4 * gi + 1], dk0[4 * gi + 2], dk0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(pk + 32 + 8 * gi + 4 * h) = f32x4{dk1[4 * gi], dk1[4 * gi + 1], dk1[4 * gi + 2], dk1[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(pv2 + 8 * gi + 4 * h) = f32x4{dv0[4 * gi], dv0[4 * gi + 1], dv0[4 * gi + 2], dv0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(pv2 + 32 + 8 * gi + 4 * h) = f32x4{dv1[4 * gi], dv1[4 * gi + 1], dv1[4 * gi + 2], dv1[4 * gi + 3]};
+    }
+    return;
+  }
+  if (!k_ok || (p.skip_global && is_global(p.pat, k))) return;
+  T* DK = reinterpret_cast<T*>(p.dk) + (long)b * p.ks[0] + (long)k * p.ks[1] + (long)n * p.ks[2];
+  T* DV = reinterpret_cast<T*>(p.dv) + (long)b * p.vs[0] + (long)k * p.vs[1] + (long)n * p.vs[2];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const int d = 8 * gi + 4 * h;
+    if constexpr (sizeof(T) == 2) {
+      bf16x4 x, y, z, u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        x[j] = (__bf16)dk0[4 * gi + j]; y[j] = (__bf16)dk1[4 * gi + j];
+        z[j] = (__bf16)dv0[4 * gi + j]; u[j] = (__bf16)dv1[4 * gi + j];
+      }
+      *reinterpret_cast<bf16x4*>(DK + d) = x; *reinterpret_cast<bf16x4*>(DK + 32 + d) = y;
+      *reinterpret_cast<bf16x4*>(DV + d) = z; *reinterpret_cast<bf16x4*>(DV + 32 + d) = u;
+    } else {
+      *reinterpret_cast<f32x4*>(DK + d) = f32x4{dk0[4 * gi], dk0[4 * gi + 1], dk0[4 * gi + 2], dk0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(DK + 32 + d) = f32x4{dk1[4 * gi], dk1[4 * gi + 1], dk1[4 * gi + 2], dk1[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(DV + d) = f32x4{dv0[4 * gi], dv0[4 * gi + 1], dv0[4 * gi + 2], dv0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(DV + 32 + d) = f32x4{dv1[4 * gi], dv1[4 * gi + 1], dv1[4 * gi + 2], dv1[4 * gi + 3]};
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_combine_kernel(const BwdParams p) {
+  const int bn = blockIdx.y, row = blockIdx.x, d = threadIdx.x;
+  const int gblk = row >> 5, rr = row & 31;
+  const int b = bn / p.N, n = bn - b * p.N;
+  const int k = p.pat.g0 + row;
+  const long slot0 = ((long)bn * p.n_gblk + gblk) * p.n_chunks;
+  float ak = 0.f, av = 0.f;
+  for (int c = 0; c < p.n_chunks; ++c) {
+    const float* base = p.part_dkv + (slot0 + c) * (2 * 32 * 64) + rr * 64 + d;
+    ak += base[0];
+    av += base[32 * 64];
+  }
+  reinterpret_cast<T*>(p.dk)[(long)b * p.ks[0] + (long)k * p.ks[1] + (long)n * p.ks[2] + d] = (T)ak;
+  reinterpret_cast<T*>(p.dv)[(long)b * p.vs[0] + (long)k * p.vs[1] + (long)n * p.vs[2] + d] = (T)av;
+}
+
+// =========================================================================================
+// K4c: dE[id,n,:] = sum_{b,q} dRel[b,n,q,id] * Q[b,q,n,:],  dbias[id,n] = sum dRel.
+// Stage 1: grid (n_split, N), 256 threads; thread t owns id = t / 8 (+32) and 8 head dims.
+// Stage 2: fixed-order sum of the n_split partials.
+// =========================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void drel_reduce1_kernel(const BwdParams p) {
+  const int n = blockIdx.y, split = blockIdx.x, t = threadIdx.x;
+  const int id0 = t >> 3, d0 = (t & 7) * 8;
+  const long rows = (long)p.B * p.S;
+  const long per = (rows + p.n_split - 1) / p.n_split;
+  const long lo = split * per, hi = min(rows, lo + per);
+  float acc[2][8] = {{0}}, bs[2] = {0.f, 0.f};
+  for (long row = lo; row < hi; ++row) {
+    const int b = (int)(row / p.S), q = (int)(row - (long)b * p.S);
+    const T* qr = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)q * p.qs[1] + (long)n * p.qs[2] + d0;
+    float qv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qv[j] = (float)qr[j];
+    const float* dr = p.drel + (((long)b * p.N + n) * p.S + q) * p.Rp;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u * 32 < p.Rp) {
+        const float x = dr[u * 32 + id0];
+        bs[u] += x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[u][j] = fmaf(x, qv[j], acc[u][j]);
+      }
+    }
+  }
+  float* out = p.part_red + ((long)n * p.n_split + split) * (p.Rp * 64 + p.Rp);
+  for (int u = 0; u < 2; ++u) {
+    if (u * 32 < p.Rp) {
+      const int id = u * 32 + id0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[id * 64 + d0 + j] = acc[u][j];
+      if ((t & 7) == 0) out[p.Rp * 64 + id] = bs[u];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void drel_reduce2_kernel(const BwdParams p) {
+  const int n = blockIdx.x;
+  const int per = p.Rp * 64 + p.Rp;
+  for (int i = threadIdx.x; i < per; i += 256) {
+    float acc = 0.f;
+    for (int s = 0; s < p.n_split; ++s) acc += p.part_red[((long)n * p.n_split + s) * per + i];
+    if (i < p.Rp * 64) {
+      const int id = i >> 6, d = i & 63;
+      if (id < p.R) p.drel_emb[((long)id * p.N + n) * 64 + d] = acc;
+    } else {
+      const int id = i - p.Rp * 64;
+      if (id < p.R && p.drel_bias) p.drel_bias[(long)id * p.N + n] = acc;
+    }
+  }
+}
+
+// ------------------------------------ launchers -----------------------------------------
+template <typename K>
+static void allow_lds(K kernel, int bytes) {
+  if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+template <typename T, int MODE, int Rp, bool GEN>
+static hipError_t launch_bwd_one(const BwdParams& p, hipStream_t st) {
+  const int per_bn = (p.n_chunks * p.n_gblk + 3) / 4;
+  dim3 grid(p.n_band_blocks + (MODE == kBand ? per_bn * p.B * p.N : 0));
+  const int lds_a = 4 * BwdLds<T, Rp>::kDq, lds_b = 4 * BwdLds<T, Rp>::kDkv;
+  allow_lds(attn_bwd_dq_kernel<T, MODE, Rp, GEN>, lds_a);
+  allow_lds(attn_bwd_dkv_kernel<T, MODE, Rp, GEN>, lds_b);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, MODE, Rp, GEN>), grid, dim3(256), lds_a, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (MODE == kBand && p.n_gblk > 0) {
+    hipLaunchKernelGGL(attn_bwd_dq_combine_kernel<T>, dim3(p.pat.ng, p.B * p.N), dim3(64), 0, st, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, MODE, Rp, GEN>), grid, dim3(256), lds_b, st, p);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (MODE == kBand && p.n_gblk > 0) {
+    hipLaunchKernelGGL(attn_bwd_dkv_combine_kernel<T>, dim3(p.pat.ng, p.B * p.N), dim3(64), 0, st, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  if (p.R > 0) {
+    hipLaunchKernelGGL(drel_reduce1_kernel<T>, dim3(p.n_split, p.N), dim3(256), 0, st, p);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(drel_reduce2_kernel, dim3(p.N), dim3(256), 0, st, p);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+template <typename T, int MODE, bool GEN>
+static hipError_t launch_bwd_rp(const BwdParams& p, hipStream_t st) {
+  if (p.Rp == 32) return launch_bwd_one<T, MODE, 32, GEN>(p, st);
+  return launch_bwd_one<T, MODE, 64, GEN>(p, st);
+}
+
+template <typename T>
+static hipError_t launch_bwd_t(const BwdParams& p, int mode, hipStream_t st) {
+  if (mode == kDense) return launch_bwd_rp<T, kDense, true>(p, st);
+  const bool gen = !(p.pat.id_mode == 0 || p.perm_1d);
+  return gen ? launch_bwd_rp<T, kBand, true>(p, st) : launch_bwd_rp<T, kBand, false>(p, st);
+}
+
+hipError_t launch_attn_bwd(const BwdParams& p, int mode, bool bf16, hipStream_t st) {
+  return bf16 ? launch_bwd_t<__bf16>(p, mode, st) : launch_bwd_t<float>(p, mode, st);
+}
+
+}  // namespace mmt

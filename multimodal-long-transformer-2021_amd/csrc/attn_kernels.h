@@ -35,6 +35,35 @@ struct FwdParams {
 hipError_t launch_attn_fwd(const FwdParams& p, int mode, bool bf16, hipStream_t st);
 hipError_t launch_rows_combine(const FwdParams& p, bool bf16, hipStream_t st);
 
+struct BwdParams {
+  const void *q, *k, *v, *emb, *bias, *out, *dout;
+  const float* lse;
+  const int32_t *att_mask, *rel_ids;
+  const int32_t* valid_len;
+  void *dq, *dk, *dv;
+  float *drel_emb, *drel_bias;        // outputs [R,N,64], [R,N] fp32
+  int B, S, N, R, Rp;
+  long qs[3], ks[3], vs[3], os[3];    // q/dq, k/dk, v/dv, out/dout
+  float sscale, tscale, mask_add;     // as FwdParams (log2 domain)
+  float gscale;                       // d(content) = ds * gscale        (= scale)
+  float rel_gscale;                   // d(rel)     = ds * rel_gscale    (= scale, or 1)
+  PatternDev pat;
+  int perm_1d;
+  int skip_global;                    // band items leave global rows / keys to the split items
+  uint32_t drop_thresh, seed_lo, seed_hi;
+  float inv_keep;
+  // workspace
+  float* delta;      // [B,N,S]       rowsum(dO * O)
+  float* drel;       // [B,N,S,Rp]    d(relall), id order
+  float* part_dq;    // [B*N, n_gblk, n_chunks, 32, 64]   global-row partials
+  float* part_dtab;  // [B*N, n_gblk, n_chunks, 32, Rp]
+  float* part_dkv;   // [B*N, n_gblk, n_chunks, 2, 32, 64] global-key partials
+  float* part_red;   // [N, n_split, Rp*64 + Rp]           dE / dbias partials
+  int n_band_blocks, n_chunks, chunk_tiles, n_gblk, n_split;
+};
+
+hipError_t launch_attn_bwd(const BwdParams& p, int mode, bool bf16, hipStream_t st);
+
 struct SideParams {
   PatternDev pat;
   int B, S;

@@ -3,6 +3,7 @@
 // global mutable state (the error message is thread-local).
 #include "../../include/mmt_attn.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -30,6 +31,8 @@ struct Plan {
   int n_rowblk, n_chunks;
   size_t fwd_ws;     // bytes
   size_t bwd_ws;
+  int n_split;
+  size_t off_delta, off_drel, off_pdq, off_pdtab, off_pdkv, off_red;  // float offsets
 };
 
 int check_desc(const mmt_attn_desc* d) {
@@ -81,7 +84,16 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
   pl.n_rowblk = pl.split_rows ? (d->mask.n_global + 31) / 32 : 0;
   pl.n_chunks = pl.split_rows ? (n_tiles + kChunkTiles - 1) / kChunkTiles : 0;
   pl.fwd_ws = (size_t)d->B * d->N * pl.n_rowblk * pl.n_chunks * (32 * 64 + 64) * sizeof(float);
-  pl.bwd_ws = 0;
+  // backward: delta, dRel, global-row / global-key partials, dE partials (floats)
+  const size_t bn = (size_t)d->B * d->N, Rp = d->R <= 32 ? 32 : 64;
+  pl.n_split = (int)std::min<size_t>(256, ((size_t)d->B * d->S + 255) / 256);
+  pl.off_delta = 0;
+  pl.off_drel = pl.off_delta + bn * d->S;
+  pl.off_pdq = pl.off_drel + bn * d->S * Rp;
+  pl.off_pdtab = pl.off_pdq + bn * pl.n_rowblk * pl.n_chunks * (32 * 64);
+  pl.off_pdkv = pl.off_pdtab + bn * pl.n_rowblk * pl.n_chunks * (32 * Rp);
+  pl.off_red = pl.off_pdkv + bn * pl.n_rowblk * pl.n_chunks * (2 * 32 * 64);
+  pl.bwd_ws = (pl.off_red + (size_t)d->N * pl.n_split * (Rp * 64 + Rp)) * sizeof(float);
   return pl;
 }
 
@@ -117,7 +129,7 @@ const char* mmt_last_error(void) { return g_err; }
 
 size_t mmt_workspace_bytes(const mmt_attn_desc* desc) {
   if (check_desc(desc) != MMT_OK) return 0;
-  Plan pl = make_plan(desc, false);
+  Plan pl = make_plan(desc, false);   // the structured plan is a superset of the dense one
   return pl.fwd_ws > pl.bwd_ws ? pl.fwd_ws : pl.bwd_ws;
 }
 
@@ -164,11 +176,48 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   return MMT_OK;
 }
 
-int mmt_attn_bwd(const mmt_attn_desc* desc, const void*, const void*, const void*, const void*,
-                 const void*, const int32_t*, const int32_t*, const void*, const void*,
-                 const float*, void*, void*, void*, float*, float*, void*, size_t, void*) {
+int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const void* v,
+                 const void* rel_emb, const void* rel_bias, const int32_t* att_mask,
+                 const int32_t* rel_ids, const void* out, const void* dout, const float* lse,
+                 void* dq, void* dk, void* dv, float* drel_emb, float* drel_bias,
+                 void* workspace, size_t workspace_bytes, void* stream) {
   if (int rc = check_desc(desc)) return rc;
-  return fail(MMT_E_UNSUPPORTED, "mmt_attn_bwd: not built yet");
+  if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv)
+    return fail(MMT_E_INVALID, "q, k, v, out, dout, lse, dq, dk, dv must not be NULL");
+  if (desc->R > 0 && (!rel_emb || !drel_emb)) return fail(MMT_E_INVALID, "R > 0 but rel_emb / drel_emb is NULL");
+  const bool dense = att_mask != nullptr || rel_ids != nullptr;
+  const Plan pl = make_plan(desc, dense);
+  if (!workspace || workspace_bytes < pl.bwd_ws)
+    return fail(MMT_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", pl.bwd_ws, workspace_bytes);
+
+  mmt::FwdParams f;
+  fill_common(f, desc);
+  mmt::BwdParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.q = q; p.k = k; p.v = v; p.emb = rel_emb; p.bias = rel_bias; p.out = out; p.dout = dout; p.lse = lse;
+  p.att_mask = att_mask; p.rel_ids = rel_ids; p.valid_len = f.valid_len;
+  p.dq = dq; p.dk = dk; p.dv = dv; p.drel_emb = drel_emb; p.drel_bias = rel_bias ? drel_bias : nullptr;
+  p.B = f.B; p.S = f.S; p.N = f.N; p.R = f.R; p.Rp = desc->R <= 32 ? 32 : 64;
+  for (int i = 0; i < 3; ++i) { p.qs[i] = f.qs[i]; p.ks[i] = f.ks[i]; p.vs[i] = f.vs[i]; p.os[i] = f.os[i]; }
+  p.sscale = f.sscale; p.tscale = f.tscale; p.mask_add = f.mask_add;
+  p.gscale = desc->scale;
+  p.rel_gscale = (desc->flags & MMT_FLAG_SCALE_BEFORE_ADD) ? 1.f : desc->scale;
+  p.pat = f.pat;
+  if (desc->R == 0) { p.pat.id_mode = 0; p.rel_ids = nullptr; }
+  p.perm_1d = (!dense && p.pat.id_mode == MMT_IDS_1D && desc->R >= 2 * p.pat.m + 1) ? 1 : 0;
+  p.drop_thresh = f.drop_thresh; p.seed_lo = f.seed_lo; p.seed_hi = f.seed_hi; p.inv_keep = f.inv_keep;
+  float* ws = reinterpret_cast<float*>(workspace);
+  p.delta = ws + pl.off_delta; p.drel = ws + pl.off_drel; p.part_dq = ws + pl.off_pdq;
+  p.part_dtab = ws + pl.off_pdtab; p.part_dkv = ws + pl.off_pdkv; p.part_red = ws + pl.off_red;
+  p.n_band_blocks = desc->B * desc->N * ((desc->S + 127) / 128);
+  p.n_split = pl.n_split;
+  if (pl.split_rows) {
+    p.skip_global = 1; p.n_gblk = pl.n_rowblk; p.n_chunks = pl.n_chunks; p.chunk_tiles = kChunkTiles;
+  }
+  hipError_t e = mmt::launch_attn_bwd(p, dense ? mmt::kDense : mmt::kBand, desc->dtype == MMT_BF16,
+                                      reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return fail(MMT_E_LAUNCH, "backward launch: %s", hipGetErrorString(e));
+  return MMT_OK;
 }
 
 int mmt_side_inputs(const mmt_mask_desc* mask, int32_t B, int32_t S,

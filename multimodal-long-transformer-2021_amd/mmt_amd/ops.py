@@ -157,3 +157,62 @@ def side_inputs(pattern: AttentionPattern, num_image_wordpieces: torch.Tensor,
     _lib.check(_lib.lib().mmt_side_inputs(desc, B, S, ptr(img), ptr(txt), int(materialize_pattern),
                                           ptr(mask), ptr(ids), ptr(seg), _stream_ptr(dev)))
   return {'segment_ids': seg, 'att_mask': mask, 'relative_att_ids': ids}
+
+
+def relative_attention_backward(dout, q, k, v, rel_emb, rel_bias, out, lse, *, att_mask=None,
+                                relative_att_ids=None, pattern: Optional[AttentionPattern] = None,
+                                valid_len=None, scale=None, mask_value=-10000.0,
+                                scale_before_add=False, dropout_p=0.0, dropout_seed=0):
+  """Backward of `relative_attention_forward` (recomputes P from `lse`).
+
+  Returns (dq, dk, dv, drel_emb, drel_bias); the table gradients are fp32."""
+  R = _check_inputs(q, k, v, rel_emb, rel_bias, att_mask, relative_att_ids, valid_len)
+  B, S, N, D = q.shape
+  dout = dout if dout.stride() == out.stride() else dout.contiguous()
+  if out.stride() != dout.stride():
+    out = out.contiguous()
+  dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+  if dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != v.stride():
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+  drel_emb = torch.empty((R, N, D), dtype=torch.float32, device=q.device) if R else None
+  drel_bias = torch.empty((R, N), dtype=torch.float32, device=q.device) if (R and rel_bias is not None) else None
+  desc = _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_before_add,
+                    dropout_p, dropout_seed)
+  L = _lib.lib()
+  ws_bytes = L.mmt_workspace_bytes(desc)
+  ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=q.device)
+  ptr = lambda t: None if t is None else t.data_ptr()
+  with torch.cuda.device(q.device):
+    _lib.check(L.mmt_attn_bwd(desc, ptr(q), ptr(k), ptr(v), ptr(rel_emb), ptr(rel_bias),
+                              ptr(att_mask), ptr(relative_att_ids), ptr(out), ptr(dout), ptr(lse),
+                              ptr(dq), ptr(dk), ptr(dv), ptr(drel_emb), ptr(drel_bias), ptr(ws),
+                              ws.numel(), _stream_ptr(q.device)))
+  return dq, dk, dv, drel_emb, drel_bias
+
+
+class _RelativeAttentionFn(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, q, k, v, rel_emb, rel_bias, kw):
+    out, lse = relative_attention_forward(q, k, v, rel_emb, rel_bias, **kw)
+    ctx.save_for_backward(q, k, v, rel_emb, rel_bias, out, lse)
+    ctx.kw = kw
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    q, k, v, rel_emb, rel_bias, out, lse = ctx.saved_tensors
+    kw = {a: b for a, b in ctx.kw.items() if a != 'return_lse'}
+    dq, dk, dv, de, db = relative_attention_backward(dout, q, k, v, rel_emb, rel_bias, out, lse, **kw)
+    de = None if de is None else de.to(rel_emb.dtype)
+    db = None if db is None else db.to(rel_bias.dtype)
+    return dq, dk, dv, de, db, None
+
+
+def relative_attention(q, k, v, rel_emb=None, rel_bias=None, **kw):
+  """Differentiable QkvRelativeAttention (see module docstring); kwargs as
+  `relative_attention_forward` (att_mask / relative_att_ids or pattern / valid_len, scale,
+  mask_value, scale_before_add, dropout_p, dropout_seed)."""
+  kw.pop('return_lse', None)
+  return _RelativeAttentionFn.apply(q, k, v, rel_emb, rel_bias, kw)

@@ -1,0 +1,92 @@
+"""Backward parity: HIP kernels (through the C ABI + autograd) vs the analytic CPU oracle.
+
+Tolerances: fp32 path 2e-3 absolute (gradients are O(1..10); observed ~1e-5); bf16 path is
+compared against the fp64 oracle run on bf16-rounded inputs, relative to each gradient's
+max magnitude (3e-2: bf16 outputs + bf16 P/dS operands)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import attention as oa
+from tests._cases import attention_inputs, bf16_round, dense_side_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bwd(B, S, N, R, dtype, *, dense, valid=None, radius=1 << 30, g0=0, ng=0, id_mode=1, m=3,
+            P=0, r=0, seed=0, scale_before_add=False, use_bias=True):
+  import mmt_amd
+  q, k, v, emb, bias = attention_inputs(B, S, N, R, seed)
+  rng = np.random.default_rng(seed + 100)
+  dout = rng.standard_normal(q.shape).astype(np.float32)
+  if not use_bias:
+    bias = None
+  if dtype == torch.bfloat16:
+    q, k, v, dout = (bf16_round(x) for x in (q, k, v, dout))
+    emb = None if emb is None else bf16_round(emb)
+    bias = None if bias is None else bf16_round(bias)
+  if R == 0:
+    id_mode = 0
+  mask, ids = dense_side_inputs(B, S, valid, radius, g0, ng, id_mode, m, P, r)
+  ref = oa.relative_attention_bwd(dout, q, k, v, emb, bias, mask, ids,
+                                  scale_after_add=not scale_before_add)
+  dev = lambda x, dt=dtype: None if x is None else torch.from_numpy(x).cuda().to(dt).contiguous()
+  tq, tk, tv, te, tb = (None if x is None else dev(x).requires_grad_(True) for x in (q, k, v, emb, bias))
+  kw = dict(scale_before_add=scale_before_add)
+  if dense:
+    out = mmt_amd.relative_attention(tq, tk, tv, te, tb, att_mask=dev(mask, torch.int32),
+                                     relative_att_ids=dev(ids, torch.int32), **kw)
+  else:
+    pat = mmt_amd.AttentionPattern(local_radius=radius, global_start=g0, n_global=ng, id_mode=id_mode,
+                                   max_dist=m, patches_per_row=P, core_layers=r)
+    vl = None if valid is None else torch.tensor(valid, dtype=torch.int32, device='cuda:0')
+    out = mmt_amd.relative_attention(tq, tk, tv, te, tb, pattern=pat, valid_len=vl, **kw)
+  out.backward(dev(dout))
+  torch.cuda.synchronize()
+  worst = 0.0
+  for name, t in (('dq', tq), ('dk', tk), ('dv', tv), ('drel_emb', te), ('drel_bias', tb)):
+    if t is None:
+      continue
+    got = t.grad.float().cpu().numpy()
+    want = ref[name]
+    assert np.isfinite(got).all(), name
+    if dtype == torch.float32:
+      err = np.abs(got - want).max()
+      assert err < 2e-3, f'{name}: max abs err {err}'
+    else:
+      err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
+      assert err < 3e-2, f'{name}: max err relative to max |grad| = {err}'
+    worst = max(worst, err)
+  return worst
+
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('cfg', [
+    dict(B=2, S=96, N=2, R=9),
+    dict(B=1, S=100, N=2, R=32, m=12, valid=[61]),
+    dict(B=1, S=64, N=1, R=0),
+    dict(B=1, S=96, N=2, R=5, m=3),                              # ids >= R contribute 0
+    dict(B=1, S=96, N=2, R=49, id_mode=2, m=12, P=6, r=2),
+    dict(B=1, S=96, N=2, R=9, scale_before_add=True),
+    dict(B=1, S=96, N=2, R=9, use_bias=False),
+], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'R', 'id_mode')))
+def test_dense_operator_backward(cfg, dtype):
+  run_bwd(dtype=dtype, dense=True, **cfg)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('cfg', [
+    dict(B=2, S=256, N=2, R=32, radius=1 << 30, m=12),
+    dict(B=2, S=256, N=2, R=32, radius=16, m=12),
+    dict(B=2, S=256, N=2, R=32, radius=16, g0=200, ng=8, m=12),
+    dict(B=2, S=300, N=2, R=32, radius=64, g0=250, ng=8, m=12, valid=[300, 211]),
+    dict(B=1, S=256, N=1, R=32, radius=0, g0=3, ng=40, m=12),
+    dict(B=1, S=200, N=2, R=49, radius=20, g0=150, ng=5, id_mode=2, m=12, P=10, r=2),
+    dict(B=1, S=96, N=1, R=0, radius=8, g0=0, ng=1),
+    dict(B=1, S=512, N=2, R=32, radius=64, g0=400, ng=8, m=12),
+], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'id_mode')))
+def test_structured_pattern_backward(cfg, dtype):
+  run_bwd(dtype=dtype, dense=False, **cfg)
