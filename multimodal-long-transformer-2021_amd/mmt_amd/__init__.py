@@ -7,5 +7,12 @@ from . import _lib
 from .ops import (AttentionPattern, relative_attention, relative_attention_backward,
                   relative_attention_forward, side_inputs)
 
-__all__ = ['AttentionPattern', 'relative_attention', 'relative_attention_forward',
+from .encoder import MmtEncoder
+from .models import MmtClassificationModel, MmtPretrainingModel
+from .benchmarks import make_train_step_bench
+from . import configs, distribute, input_utils, layers, optimization, registry_imports, tasks
+
+__all__ = ['MmtEncoder', 'MmtPretrainingModel', 'MmtClassificationModel', 'make_train_step_bench',
+           'configs', 'tasks', 'distribute', 'optimization', 'layers', 'input_utils',
+           'AttentionPattern', 'relative_attention', 'relative_attention_forward',
            'relative_attention_backward', 'side_inputs', '_lib']

@@ -1,0 +1,141 @@
+"""Data-parallel training over RCCL/xGMI: one process per GPU, gradients all-reduced in
+buckets that overlap the backward pass.
+
+Replaces `src/distribute_utils.py:97-188` (tf.distribute strategy factory; the gradient
+all-reduce is implicit in `optimizer.apply_gradients`, `src/tasks/pretraining.py:273`).
+The reference SUMs per-replica gradients (and divides the loss by `num_replicas_in_sync`
+only with `scale_loss=True`, pretraining.py:286-296); `reduce='mean'` is this build's default
+and `reduce='sum'` reproduces the reference default -- SURVEY.md 8(e).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+_VALID = ('off', 'one_device', 'mirrored', 'multi_worker_mirrored', 'tpu', 'parameter_server')
+
+
+class DataParallelStrategy:
+  """What `get_distribution_strategy` returns: rank/world bookkeeping + the gradient reducer."""
+
+  def __init__(self, backend: Optional[str], bucket_mb: float = 48.0):
+    self.backend = backend
+    self.bucket_bytes = int(bucket_mb * (1 << 20))
+    self.rank = dist.get_rank() if backend else 0
+    self.num_replicas_in_sync = dist.get_world_size() if backend else 1
+
+  def make_reducer(self, params: List[torch.nn.Parameter], reduce: str = 'mean'):
+    return GradientBucketReducer(params, self, reduce)
+
+
+def get_distribution_strategy(distribution_strategy='mirrored', num_gpus=0, all_reduce_alg=None,
+                              num_packs=1, tpu_address=None, zone=None, bucket_mb=48.0, **kwargs):
+  """Same argument checks as `distribute_utils.get_distribution_strategy` (:136-188); every
+  multi-device strategy maps to one-process-per-GPU data parallelism over RCCL (`nccl` backend
+  on ROCm) or gloo on CPU."""
+  del kwargs, num_packs, tpu_address, zone
+  if num_gpus < 0:
+    raise ValueError('`num_gpus` can not be negative.')
+  if not isinstance(distribution_strategy, str):
+    msg = 'distribution_strategy must be a string but got: %s.' % (distribution_strategy,)
+    if distribution_strategy == False:  # noqa: E712  (yaml `off` -> False, as in the reference)
+      msg += (" If you meant to pass the string 'off', make sure you add quotes around 'off' "
+              'so that yaml interprets it as a string instead of a bool.')
+    raise ValueError(msg)
+  name = distribution_strategy.lower()
+  if name not in _VALID:
+    raise ValueError('Unrecognized Distribution Strategy: %r' % distribution_strategy)
+  if name in ('off', 'one_device'):
+    if num_gpus > 1:
+      raise ValueError('When {} GPUs are specified, distribution_strategy flag cannot be set '
+                       'to `off`.'.format(num_gpus) if name == 'off' else
+                       '`OneDeviceStrategy` can not be used for more than one device.')
+    return DataParallelStrategy(None, bucket_mb)
+  if name in ('tpu', 'parameter_server'):
+    raise ValueError(f'{name} strategy is not available on MI355X; use `mirrored`.')
+  if all_reduce_alg not in (None, 'nccl', 'ring', 'hierarchical_copy'):
+    raise ValueError(f'unknown all_reduce_alg {all_reduce_alg!r}')
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  if world == 1:
+    return DataParallelStrategy(None, bucket_mb)
+  if not dist.is_initialized():
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    kw = {}
+    if backend == 'nccl':
+      kw['device_id'] = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    dist.init_process_group(backend, **kw)
+  return DataParallelStrategy(dist.get_backend(), bucket_mb)
+
+
+class GradientBucketReducer:
+  """Flat fp32 gradient buckets, filled in reverse parameter order; each bucket's all-reduce is
+  launched (async, on RCCL's stream) as soon as its last gradient has been accumulated, so the
+  exchange overlaps the rest of backward.  `param.grad` are views into the buckets: no copies."""
+
+  def __init__(self, params, strategy: DataParallelStrategy, reduce: str = 'mean'):
+    if reduce not in ('mean', 'sum'):
+      raise ValueError("reduce must be 'mean' or 'sum'")
+    self.strategy, self.reduce = strategy, reduce
+    self.world = strategy.num_replicas_in_sync
+    self.params = [p for p in params if p.requires_grad]
+    self.buckets: List[torch.Tensor] = []
+    self._bucket_of, self._pending, self._handles = {}, [], []
+    order = list(reversed(self.params))
+    cur, cur_bytes = [], 0
+    groups = []
+    for p in order:
+      nbytes = p.numel() * 4
+      if cur and cur_bytes + nbytes > strategy.bucket_bytes:
+        groups.append(cur); cur, cur_bytes = [], 0
+      cur.append(p); cur_bytes += nbytes
+    if cur:
+      groups.append(cur)
+    for gi, group in enumerate(groups):
+      flat = torch.zeros(sum(p.numel() for p in group), dtype=torch.float32, device=group[0].device)
+      off = 0
+      for p in group:
+        p.grad = flat[off:off + p.numel()].view_as(p)
+        off += p.numel()
+        self._bucket_of[p] = gi
+      self.buckets.append(flat)
+      self._pending.append(len(group))
+    self._group_sizes = list(self._pending)
+    if self.world > 1:
+      for p in self.params:
+        p.register_post_accumulate_grad_hook(self._on_grad_ready)
+
+  def zero_grad(self):
+    for b in self.buckets:
+      b.zero_()
+    self._pending = list(self._group_sizes)
+    self._handles = []
+
+  def _on_grad_ready(self, p):
+    gi = self._bucket_of[p]
+    self._pending[gi] -= 1
+    if self._pending[gi] == 0:
+      self._handles.append(dist.all_reduce(self.buckets[gi], op=dist.ReduceOp.SUM, async_op=True))
+
+  def finish(self):
+    """Waits for the outstanding all-reduces and applies the mean (if requested)."""
+    if self.world > 1:
+      for gi, left in enumerate(self._pending):     # parameters that received no gradient
+        if left > 0:
+          self._handles.append(dist.all_reduce(self.buckets[gi], op=dist.ReduceOp.SUM, async_op=True))
+      for h in self._handles:
+        h.wait()
+      if self.reduce == 'mean':
+        for b in self.buckets:
+          b.mul_(1.0 / self.world)
+    self._handles = []
+
+  def clip_by_global_norm(self, max_norm: float) -> torch.Tensor:
+    total = torch.sqrt(sum((b.float() ** 2).sum() for b in self.buckets))
+    scale = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for b in self.buckets:
+      b.mul_(scale)
+    return total

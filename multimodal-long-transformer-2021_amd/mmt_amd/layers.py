@@ -1,0 +1,307 @@
+"""Layers of the hot path, mirroring the pieces of `etcmodel.layers` / TF-Model-Garden that
+`MmtEncoder` and the two model wrappers instantiate.
+
+Reference call sites: `src/modeling/models/mmt_encoder.py:90-135` (EmbeddingLookup,
+RelativeTransformerLayers), `mmt_pretraining_model.py:91-103` (MaskedLM, MaskedPP),
+`tasks/pretraining.py:75-78` (ClassificationHead).  Semantics per SURVEY.md App. A.1-A.3.
+torch is the buffer carrier / autograd glue; the attention core runs in the HIP kernels.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def truncated_normal_(t: torch.Tensor, stddev: float) -> torch.Tensor:
+  """tf.keras.initializers.TruncatedNormal: resampled beyond two standard deviations."""
+  return nn.init.trunc_normal_(t, mean=0.0, std=stddev, a=-2 * stddev, b=2 * stddev)
+
+
+def get_activation(name_or_fn) -> Optional[Callable]:
+  """'gelu' is the tanh approximation, as in the reference encoder
+  (`mmt_encoder.py:53-54`; TFM `tf_utils.get_activation('gelu')` is also approximate)."""
+  if name_or_fn is None or callable(name_or_fn):
+    return name_or_fn
+  table = {'gelu': lambda x: F.gelu(x, approximate='tanh'), 'relu': F.relu, 'tanh': torch.tanh,
+           'linear': None, 'identity': None}
+  if name_or_fn not in table:
+    raise ValueError(f'unknown activation {name_or_fn!r}')
+  return table[name_or_fn]
+
+
+def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+  """x @ W^T + b in x's dtype (fp32 master weights, bf16 compute)."""
+  return F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
+
+
+class EmbeddingLookup(nn.Module):
+  """etc_layers.EmbeddingLookup (ctor args as at `mmt_encoder.py:90-95`): table [V,E], an
+  optional projection when projection_size != embedding_size.  One-hot and gather lookups
+  agree for in-range ids (App. A.4 (7)), so `use_one_hot_lookup` only documents intent."""
+
+  def __init__(self, vocab_size: int, embedding_size: int, projection_size: Optional[int] = None,
+               initializer_range: float = 0.02, use_one_hot_lookup: bool = False, name: str = ''):
+    super().__init__()
+    self.vocab_size, self.embedding_size = vocab_size, embedding_size
+    self.projection_size = projection_size
+    self.initializer_range = initializer_range
+    self.use_one_hot_lookup = use_one_hot_lookup
+    self.name = name
+    self.embedding_table = nn.Parameter(torch.empty(vocab_size, embedding_size))
+    truncated_normal_(self.embedding_table, initializer_range)
+    if projection_size is not None and projection_size != embedding_size:
+      self.embedding_projection = nn.Parameter(torch.empty(projection_size, embedding_size))
+      truncated_normal_(self.embedding_projection, initializer_range)
+    else:
+      self.embedding_projection = None
+
+  def forward(self, ids: torch.Tensor) -> torch.Tensor:
+    out = F.embedding(ids.long(), self.embedding_table)
+    if self.embedding_projection is not None:
+      out = F.linear(out, self.embedding_projection)
+    return out
+
+
+class RelativeAttention(nn.Module):
+  """etc_layers.RelativeAttention: Q/K/V projections (one fused [3H,H] GEMM), the
+  QkvRelativeAttention core (HIP kernels), output projection.  App. A.3 `inner_att`."""
+
+  def __init__(self, hidden_size: int, num_heads: int, relative_vocab_size: Optional[int],
+               att_dropout_prob: float, initializer_range: float, use_relative_bias: bool = True):
+    super().__init__()
+    if hidden_size % num_heads:
+      raise ValueError('`hidden_size` must be a multiple of `num_heads`.')
+    self.hidden_size, self.num_heads = hidden_size, num_heads
+    self.head_size = hidden_size // num_heads
+    self.att_dropout_prob = att_dropout_prob
+    self.qkv_weight = nn.Parameter(torch.empty(3 * hidden_size, hidden_size))
+    self.qkv_bias = nn.Parameter(torch.zeros(3 * hidden_size))
+    self.output_weight = nn.Parameter(torch.empty(hidden_size, hidden_size))
+    self.output_bias = nn.Parameter(torch.zeros(hidden_size))
+    truncated_normal_(self.qkv_weight, initializer_range)
+    truncated_normal_(self.output_weight, initializer_range)
+    if relative_vocab_size:
+      self.relative_emb_table = nn.Parameter(
+          torch.empty(relative_vocab_size, num_heads, self.head_size))
+      truncated_normal_(self.relative_emb_table, initializer_range)
+      if use_relative_bias:
+        self.relative_bias_table = nn.Parameter(torch.empty(relative_vocab_size, num_heads))
+        truncated_normal_(self.relative_bias_table, initializer_range)
+      else:
+        self.relative_bias_table = None
+    else:
+      self.relative_emb_table = self.relative_bias_table = None
+    self._calls = 0
+
+  def forward(self, x, att_mask=None, relative_att_ids=None, pattern=None, valid_len=None,
+              training=False, dropout_seed=0):
+    B, S, H = x.shape
+    qkv = _linear(x, self.qkv_weight, self.qkv_bias).view(B, S, 3, self.num_heads, self.head_size)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    emb = None if self.relative_emb_table is None else self.relative_emb_table.to(x.dtype)
+    bias = None if self.relative_bias_table is None else self.relative_bias_table.to(x.dtype)
+    if relative_att_ids is None and (pattern is None or pattern.id_mode == 0):
+      emb = bias = None
+    self._calls += 1
+    p_drop = self.att_dropout_prob if training else 0.0
+    out = ops.relative_attention(
+        q, k, v, emb, bias, att_mask=att_mask, relative_att_ids=relative_att_ids, pattern=pattern,
+        valid_len=valid_len, dropout_p=p_drop,
+        dropout_seed=(int(dropout_seed) * 1000003 + self._calls) if p_drop > 0 else 0)
+    return _linear(out.reshape(B, S, H), self.output_weight, self.output_bias)
+
+
+class RelativeTransformerLayer(nn.Module):
+  """ResidualBlock(RelativeAttention) + ResidualBlock(FFN) (App. A.3 `layer`)."""
+
+  def __init__(self, hidden_size, num_heads, intermediate_size, activation, hidden_dropout_prob,
+               att_dropout_prob, initializer_range, relative_vocab_size, use_pre_activation_order):
+    super().__init__()
+    self.attention = RelativeAttention(hidden_size, num_heads, relative_vocab_size,
+                                       att_dropout_prob, initializer_range)
+    self.attention_layer_norm = nn.LayerNorm(hidden_size, eps=1e-12)
+    self.ffn_layer_norm = nn.LayerNorm(hidden_size, eps=1e-12)
+    self.intermediate_weight = nn.Parameter(torch.empty(intermediate_size, hidden_size))
+    self.intermediate_bias = nn.Parameter(torch.zeros(intermediate_size))
+    self.ffn_output_weight = nn.Parameter(torch.empty(hidden_size, intermediate_size))
+    self.ffn_output_bias = nn.Parameter(torch.zeros(hidden_size))
+    truncated_normal_(self.intermediate_weight, initializer_range)
+    truncated_normal_(self.ffn_output_weight, initializer_range)
+    self.activation = activation
+    self.hidden_dropout_prob = hidden_dropout_prob
+    self.use_pre_activation_order = use_pre_activation_order
+
+  def _ln(self, ln: nn.LayerNorm, x):
+    return F.layer_norm(x, ln.normalized_shape, ln.weight.to(x.dtype), ln.bias.to(x.dtype), ln.eps)
+
+  def _ffn(self, x):
+    y = _linear(x, self.intermediate_weight, self.intermediate_bias)
+    if self.activation is not None:
+      y = self.activation(y)
+    return _linear(y, self.ffn_output_weight, self.ffn_output_bias)
+
+  def forward(self, x, training=False, **att_kw):
+    drop = lambda t: F.dropout(t, self.hidden_dropout_prob, training)
+    if self.use_pre_activation_order:   # y = x + Dropout(inner(LN(x)))
+      x = x + drop(self.attention(self._ln(self.attention_layer_norm, x), training=training, **att_kw))
+      x = x + drop(self._ffn(self._ln(self.ffn_layer_norm, x)))
+    else:                               # y = LN(x + Dropout(inner(x)))
+      x = self._ln(self.attention_layer_norm, x + drop(self.attention(x, training=training, **att_kw)))
+      x = self._ln(self.ffn_layer_norm, x + drop(self._ffn(x)))
+    return x
+
+
+class RelativeTransformerLayers(nn.Module):
+  """etc_layers.RelativeTransformerLayers with the ctor args of `mmt_encoder.py:124-135` and
+  the call contract of `:220-224`: (inputs, att_mask, relative_att_ids, training).  The
+  `pattern` / `valid_len` keywords select the structured fast path instead of dense side
+  inputs (the build's extension; equal to the dense operator on the materialised mask)."""
+
+  def __init__(self, hidden_size, num_hidden_layers, num_attention_heads, intermediate_size=None,
+               hidden_act=None, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+               initializer_range=0.02, relative_vocab_size=None, use_pre_activation_order=False,
+               use_one_hot_lookup=True):
+    super().__init__()
+    intermediate_size = intermediate_size or 4 * hidden_size
+    self.use_one_hot_lookup = use_one_hot_lookup
+    self.layers = nn.ModuleList([
+        RelativeTransformerLayer(hidden_size, num_attention_heads, intermediate_size, hidden_act,
+                                 hidden_dropout_prob, attention_probs_dropout_prob,
+                                 initializer_range, relative_vocab_size, use_pre_activation_order)
+        for _ in range(num_hidden_layers)])
+
+  def forward(self, inputs, att_mask=None, relative_att_ids=None, training=False, pattern=None,
+              valid_len=None, dropout_seed=0):
+    x = inputs
+    for i, layer in enumerate(self.layers):
+      x = layer(x, training=training, att_mask=att_mask, relative_att_ids=relative_att_ids,
+                pattern=pattern, valid_len=valid_len, dropout_seed=dropout_seed * 131 + i)
+    return x
+
+
+def gather_indexes(sequence_tensor: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
+  """`src/tensor_utils.py:27-44`: [B,S,W], [B,M] -> [B*M, W]."""
+  B, S, W = sequence_tensor.shape
+  flat_offsets = (torch.arange(B, device=positions.device) * S).view(-1, 1)
+  flat_positions = (positions.long() + flat_offsets).reshape(-1)
+  return sequence_tensor.reshape(B * S, W).index_select(0, flat_positions)
+
+
+class MaskedLM(nn.Module):
+  """TFM keras_nlp.layers.MaskedLM (output='logits'): gather -> dense(act) -> LN -> tied
+  logits + bias (`mmt_pretraining_model.py:91-96`)."""
+
+  def __init__(self, embedding_layer: EmbeddingLookup, activation=None, bind: bool = True):
+    super().__init__()
+    V, E = embedding_layer.vocab_size, embedding_layer.embedding_size
+    self._embedding_layer = [embedding_layer] if bind else None   # not a submodule: tied table
+    if not bind:
+      self.mlm_embedding_table = nn.Parameter(torch.empty(V, E))
+      truncated_normal_(self.mlm_embedding_table, embedding_layer.initializer_range)
+    self.dense_weight = nn.Parameter(torch.empty(E, E))
+    nn.init.xavier_uniform_(self.dense_weight)          # glorot_uniform
+    self.dense_bias = nn.Parameter(torch.zeros(E))
+    self.layer_norm = nn.LayerNorm(E, eps=1e-12)
+    self.output_bias = nn.Parameter(torch.zeros(V))
+    self.activation = activation
+
+  @property
+  def embedding_table(self):
+    return self._embedding_layer[0].embedding_table if self._embedding_layer else self.mlm_embedding_table
+
+  def forward(self, sequence_data, masked_positions):
+    x = gather_indexes(sequence_data, masked_positions)
+    x = _linear(x, self.dense_weight, self.dense_bias)
+    if self.activation is not None:
+      x = self.activation(x)
+    x = F.layer_norm(x, self.layer_norm.normalized_shape, self.layer_norm.weight.to(x.dtype),
+                     self.layer_norm.bias.to(x.dtype), self.layer_norm.eps)
+    logits = _linear(x, self.embedding_table, self.output_bias)
+    return logits.view(masked_positions.shape[0], masked_positions.shape[1], -1)
+
+
+class MaskedPP(nn.Module):
+  """`src/modeling/layers/masked_patch_prediction_layer.py:58-98`: gather -> LN -> dense -> bias."""
+
+  def __init__(self, hidden_size: int, output_num_classes: int, activation=None, output: str = 'logits'):
+    super().__init__()
+    if output not in ('predictions', 'logits'):
+      raise ValueError(f'Unknown `output` value "{output}". `output` can be either "logits"'
+                       f'or "predictions"')
+    self._output_type = output
+    self.layer_norm = nn.LayerNorm(hidden_size, eps=1e-12)
+    self.dense_weight = nn.Parameter(torch.empty(output_num_classes, hidden_size))
+    nn.init.xavier_uniform_(self.dense_weight)
+    self.dense_bias = nn.Parameter(torch.zeros(output_num_classes))
+    self.bias = nn.Parameter(torch.zeros(output_num_classes))
+    self.activation = activation
+
+  def forward(self, sequence_data, masked_positions):
+    x = gather_indexes(sequence_data, masked_positions)
+    x = F.layer_norm(x, self.layer_norm.normalized_shape, self.layer_norm.weight.to(x.dtype),
+                     self.layer_norm.bias.to(x.dtype), self.layer_norm.eps)
+    x = _linear(x, self.dense_weight, self.dense_bias)
+    if self.activation is not None:
+      x = self.activation(x)
+    logits = (x + self.bias.to(x.dtype)).view(masked_positions.shape[0], masked_positions.shape[1], -1)
+    return logits if self._output_type == 'logits' else F.log_softmax(logits.float(), -1)
+
+
+class ClassificationHead(nn.Module):
+  """TFM nlp ClassificationHead built from `ClsHeadConfig` (`src/configs/mmt.py:24-31`)."""
+
+  def __init__(self, hidden_size: int, inner_dim: int = 0, num_classes: int = 2,
+               activation: Optional[str] = 'tanh', dropout_rate: float = 0.0,
+               cls_token_idx: int = 0, name: Optional[str] = None):
+    super().__init__()
+    self.name = name or 'cls_head'
+    self.cls_token_idx, self.dropout_rate = cls_token_idx, dropout_rate
+    self.activation = get_activation(activation)
+    in_dim = hidden_size
+    if inner_dim:
+      self.dense_weight = nn.Parameter(torch.empty(inner_dim, hidden_size))
+      nn.init.xavier_uniform_(self.dense_weight)
+      self.dense_bias = nn.Parameter(torch.zeros(inner_dim))
+      in_dim = inner_dim
+    else:
+      self.dense_weight = None
+    self.out_proj_weight = nn.Parameter(torch.empty(num_classes, in_dim))
+    nn.init.xavier_uniform_(self.out_proj_weight)
+    self.out_proj_bias = nn.Parameter(torch.zeros(num_classes))
+
+  def forward(self, features, training=False):
+    x = features[:, self.cls_token_idx]
+    x = F.dropout(x, self.dropout_rate, training)
+    if self.dense_weight is not None:
+      x = _linear(x, self.dense_weight, self.dense_bias)
+      if self.activation is not None:
+        x = self.activation(x)
+      x = F.dropout(x, self.dropout_rate, training)
+    return _linear(x, self.out_proj_weight, self.out_proj_bias)
+
+  @property
+  def checkpoint_items(self):
+    return {'dense': self.dense_weight, 'out_proj': self.out_proj_weight}
+
+
+def weighted_sparse_categorical_crossentropy_loss(logits, labels, label_weights, metrics=None,
+                                                  name='', pos_weights=None):
+  """`src/modeling/losses/weighted_sparse_categorical_crossentropy_loss.py:17-43` incl.
+  `divide_no_nan` (an all-zero weight vector gives loss 0, App. B q13)."""
+  flat = logits.float().reshape(-1, logits.shape[-1])
+  unweighted = F.cross_entropy(flat, labels.reshape(-1).long(), reduction='none').view(labels.shape)
+  if pos_weights is not None:
+    unweighted = unweighted * pos_weights.to(unweighted.dtype)
+  w = label_weights.to(unweighted.dtype)
+  num, den = (w * unweighted).sum(), w.sum()
+  loss = torch.where(den != 0, num / torch.where(den != 0, den, torch.ones_like(den)),
+                     torch.zeros_like(num))
+  if metrics is not None:
+    metrics.setdefault(f'{name}_loss', []).append(loss.detach())
+  return loss

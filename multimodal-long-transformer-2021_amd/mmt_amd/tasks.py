@@ -1,0 +1,180 @@
+"""Task objects of the reference for the hot path: `PretrainingTask`
+(`src/tasks/pretraining.py:51-351`) and `ClassificationTask` (`src/tasks/classification.py:55-254`)
+-- build_model / build_inputs / build_losses / train_step with the reference's micro-batch
+accumulation semantics (pretraining.py:224-298)."""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, Optional
+
+import torch
+
+from . import configs, input_utils, layers, models
+
+_TASKS = {}
+
+
+def register_task_cls(config_cls):
+  def deco(cls):
+    _TASKS[config_cls] = cls
+    return cls
+  return deco
+
+
+def get_task(task_config, logging_dir=None, **kw):
+  """`task_factory.get_task`."""
+  for cfg_cls, task_cls in _TASKS.items():
+    if type(task_config) is cfg_cls:
+      return task_cls(task_config, logging_dir=logging_dir, **kw)
+  raise KeyError(f'no task registered for {type(task_config).__name__}')
+
+
+def _compute_dtype(runtime_dtype: Optional[str]) -> torch.dtype:
+  return torch.bfloat16 if runtime_dtype in ('bfloat16', 'mixed_bfloat16', 'bf16') else torch.float32
+
+
+class _TaskBase:
+  loss = 'loss'
+
+  def __init__(self, params, logging_dir=None, name=None, compute_dtype=torch.float32,
+               num_replicas: int = 1):
+    self.task_config = params
+    self.logging_dir, self.name = logging_dir, name
+    self.compute_dtype = compute_dtype
+    self.num_replicas = num_replicas
+
+  def _build_encoder(self, encoder_cfg):
+    data_cfg = self.task_config.train_data
+    return configs.build_encoder(encoder_cfg, compute_dtype=self.compute_dtype,
+                                 patch_embedding_size=data_cfg.patch_size ** 2 * 3)
+
+  def build_inputs(self, params, device='cuda', rank: int = 0, dense_side_inputs: bool = False,
+                   batch_size: Optional[int] = None, ragged: bool = False):
+    """Synthetic stand-in for the tf.data loaders: an endless iterator of (inputs, labels)
+    with the reference's feature contract; per-replica batch = global_batch_size / replicas
+    (`pretrain_dataloader.py:107-108`), seeded per rank."""
+    per_replica = batch_size or max(1, params.global_batch_size // self.num_replicas)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    vocab = self.task_config.model.encoder.get().vocab_size
+    task = 'pretrain' if isinstance(self, PretrainingTask) else 'classification'
+    def it():
+      while True:
+        yield input_utils.synthetic_batch(params, per_replica, device, gen, vocab_size=vocab,
+                                          dense_side_inputs=dense_side_inputs, ragged=ragged, task=task)
+    return it()
+
+  # ---- the reference's gradient-accumulation train step (pretraining.py:224-298) ----------
+  def train_step(self, inputs, model, optimizer, metrics: Optional[Dict] = None, reducer=None,
+                 micro_batch_size: Optional[int] = None, clip_norm: Optional[float] = None):
+    inputs, labels = inputs
+    micro = micro_batch_size or getattr(self.task_config, 'micro_batch_size', None)
+    batch_size = inputs['word_ids'].shape[0]
+    micro = micro or batch_size
+    num_small_steps = batch_size // micro
+    if num_small_steps == 0:
+      warnings.warn('per-replica batch smaller than the micro batch: zero micro-steps run '
+                    '(reference behaviour, SURVEY.md App. B q7)')
+    if reducer is not None:
+      reducer.zero_grad()
+    else:
+      optimizer.zero_grad(set_to_none=True)
+    all_loss = torch.zeros((), device=inputs['word_ids'].device)
+    is_t = lambda v: torch.is_tensor(v)
+    for i in range(num_small_steps):
+      # the reference takes the leading `micro` examples, then rotates them to the end
+      sl = slice(i * micro, (i + 1) * micro)
+      small_inputs = {k: (v[sl] if is_t(v) else v) for k, v in inputs.items()}
+      small_labels = {k: v[sl] for k, v in labels.items()}
+      outputs = model(**small_inputs, training=True)
+      loss = self.build_losses(small_labels, outputs, metrics)
+      if self.task_config.scale_loss:   # pretraining.py:286-296: gradient of loss / replicas
+        grad_loss = loss / self.num_replicas
+      else:
+        grad_loss = loss / num_small_steps
+      grad_loss.backward()
+      all_loss = all_loss + (loss / num_small_steps).detach()
+    if reducer is not None:
+      reducer.finish()                   # gradient all-reduce == optimizer.apply_gradients(:273)
+      if clip_norm:
+        reducer.clip_by_global_norm(clip_norm)
+    elif clip_norm:
+      torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
+    optimizer.step()
+    return {self.loss: all_loss}
+
+  @torch.no_grad()
+  def validation_step(self, inputs, model, metrics=None):
+    inputs, labels = inputs
+    outputs = model(**inputs, training=False)
+    return {self.loss: self.build_losses(labels, outputs, metrics)}
+
+
+@register_task_cls(configs.PretrainingTaskConfig)
+class PretrainingTask(_TaskBase):
+  """MLM + MPP + ITM pretraining."""
+
+  def build_model(self, params=None):
+    config = params or self.task_config.model
+    encoder = self._build_encoder(config.encoder)
+    data_cfg = self.task_config.train_data
+    mpp_output_num_classes = (2 ** data_cfg.output_channel_bits) ** 3        # pretraining.py:69
+    hidden = config.encoder.get().hidden_size
+    heads = [layers.ClassificationHead(hidden, **c.as_dict()) for c in config.cls_heads]
+    return models.MmtPretrainingModel(
+        encoder=encoder, mpp_output_num_classes=mpp_output_num_classes,
+        mlm_activation=config.mlm_activation, mlm_initializer=config.mlm_initializer,
+        mpp_activation=config.mpp_activation, mpp_initializer=config.mpp_initializer,
+        classification_heads=heads, bind_word_embedding_table=config.bind_word_embedding_table)
+
+  def build_losses(self, labels, model_outputs, metrics=None, aux_losses=None):
+    """`pretraining.py:95-140`."""
+    wsce = layers.weighted_sparse_categorical_crossentropy_loss
+    if 'itm_label_weights' in labels:    # mask MLM / MPP losses on negative pairs
+      itm = labels['itm_label_ids'].unsqueeze(1).float()
+      mlm_w, mpp_w = labels['mlm_label_weights'] * itm, labels['mpp_label_weights'] * itm
+    else:
+      mlm_w, mpp_w = labels['mlm_label_weights'], labels['mpp_label_weights']
+    total = wsce(model_outputs['mlm_logits'], labels['mlm_label_ids'], mlm_w, metrics, 'mlm')
+    total = total + wsce(model_outputs['mpp_logits'], labels['mpp_label_ids'], mpp_w, metrics, 'mpp')
+    if 'itm_label_weights' in labels:
+      total = total + wsce(model_outputs['itm_logits'], labels['itm_label_ids'],
+                           labels['itm_label_weights'], metrics, 'itm')
+    if aux_losses:
+      total = total + sum(aux_losses)
+    return total
+
+
+@register_task_cls(configs.ClassificationConfig)
+class ClassificationTask(_TaskBase):
+  """ITM / retrieval fine-tuning."""
+  METRIC_TYPES = frozenset(['accuracy', 'auc'])
+
+  def __init__(self, params, logging_dir=None, name=None, **kw):
+    super().__init__(params, logging_dir, name, **kw)
+    if params.metric_type not in self.METRIC_TYPES:
+      raise ValueError(f'Invalid metric_type: {params.metric_type}')
+    d = params.train_data
+    self.label_field = d.label_field or 'label_ids'
+    self.logits_field = d.logits_field or 'logits'
+    self.label_weights_field = d.label_weights_field or 'label_weights'
+    self.pos_weights_field = d.pos_weights_field or 'pos_weights'
+    self.task_name = 'classification'
+
+  def build_model(self):
+    config = self.task_config.model
+    encoder = self._build_encoder(config.encoder)
+    hidden = config.encoder.get().hidden_size
+    heads = [layers.ClassificationHead(hidden, **c.as_dict()) for c in config.cls_heads]
+    return models.MmtClassificationModel(encoder=encoder, classification_heads=heads)
+
+  def build_losses(self, labels, model_outputs, metrics=None, aux_losses=None):
+    """`classification.py:100-126` (the num_classes == 1 branch is dead in the reference, q6)."""
+    logits_key = self.logits_field
+    if logits_key not in model_outputs:      # e.g. head named 'itm' -> 'itm_logits'
+      logits_key = next(k for k in model_outputs if k.endswith('_logits'))
+    loss = layers.weighted_sparse_categorical_crossentropy_loss(
+        model_outputs[logits_key], labels[self.label_field], labels[self.label_weights_field],
+        metrics, self.task_name, pos_weights=labels.get(self.pos_weights_field))
+    if aux_losses:
+      loss = loss + sum(aux_losses)
+    return loss

@@ -1,0 +1,87 @@
+"""Training driver with the reference's flag surface (`src/train.py:37-91`):
+  python -m mmt_amd.train --experiment mmt/pretraining --mode train --model_dir /tmp/m \\
+      --config_file a.yaml --params_override task.train_data.max_seq_len=1024
+Launch one process per GPU (torchrun / torch.distributed.run); data are synthetic
+(`input_utils.synthetic_batch`) -- real-data ingestion is out of scope.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import torch
+
+from . import configs, distribute, optimization, tasks
+
+
+def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, device=None,
+                   log_every: int = 10, max_steps=None):
+  """Minimal `train_lib.run_experiment`: build task/model/optimizer under the strategy, loop."""
+  rt = params.runtime
+  strategy = distribute.get_distribution_strategy(
+      distribution_strategy=rt.distribution_strategy, all_reduce_alg=rt.all_reduce_alg,
+      num_gpus=rt.num_gpus, tpu_address=rt.tpu)
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  device = device or torch.device('cuda', local_rank)
+  torch.cuda.set_device(device)
+  task = tasks.get_task(params.task, logging_dir=model_dir,
+                        compute_dtype=tasks._compute_dtype(rt.mixed_precision_dtype),
+                        num_replicas=strategy.num_replicas_in_sync)
+  torch.manual_seed(0)     # identical initial weights on every replica
+  model = task.build_model().to(device)
+  opt_cfg = params.trainer.optimizer_config
+  optimizer = optimization.create_optimizer(model, opt_cfg)
+  reducer = strategy.make_reducer(list(model.parameters()),
+                                  reduce='sum' if not params.task.scale_loss and os.environ.get('MMT_REFERENCE_SUM') else 'mean')
+  data = task.build_inputs(params.task.train_data, device=device, rank=strategy.rank)
+  steps = max_steps or params.trainer.train_steps
+  logs = []
+  if 'train' in mode:
+    t0 = time.perf_counter()
+    for step in range(steps):
+      optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, step))
+      out = task.train_step(next(data), model, optimizer, metrics={}, reducer=reducer,
+                            clip_norm=opt_cfg.gradient_clip_norm)
+      if step % log_every == 0 or step == steps - 1:
+        loss = float(out[task.loss])
+        logs.append({'step': step, 'loss': loss, 'elapsed_s': time.perf_counter() - t0})
+        if strategy.rank == 0:
+          print(json.dumps(logs[-1]), flush=True)
+    if strategy.rank == 0 and model_dir:
+      os.makedirs(model_dir, exist_ok=True)
+      torch.save({'model': model.state_dict(), 'step': steps}, os.path.join(model_dir, 'ckpt.pt'))
+  if 'eval' in mode:
+    vdata = task.build_inputs(params.task.validation_data, device=device, rank=strategy.rank)
+    out = task.validation_step(next(vdata), model, metrics={})
+    logs.append({'validation_loss': float(out[task.loss])})
+    if strategy.rank == 0:
+      print(json.dumps(logs[-1]), flush=True)
+  return model, logs
+
+
+def main(argv=None):
+  ap = argparse.ArgumentParser(description=__doc__)
+  ap.add_argument('--experiment', required=True)
+  ap.add_argument('--mode', required=True,
+                  choices=['train', 'eval', 'train_and_eval', 'continuous_train_and_eval'])
+  ap.add_argument('--model_dir', required=True)
+  ap.add_argument('--config_file', action='append', default=[])
+  ap.add_argument('--params_override', default=None)
+  ap.add_argument('--tpu', default=None)
+  ap.add_argument('--tpu_zone', default=None)
+  ap.add_argument('--pretrain_steps', type=int, default=None)
+  ap.add_argument('--max_steps', type=int, default=None)
+  args = ap.parse_args(argv)
+  params = configs.parse_configuration(args.experiment, args.config_file, args.params_override)
+  if 'train' in args.mode and args.model_dir:
+    os.makedirs(args.model_dir, exist_ok=True)
+    with open(os.path.join(args.model_dir, 'params.yaml'), 'w') as f:
+      import yaml
+      yaml.safe_dump(params.as_dict(), f)
+  run_experiment(params, args.mode, args.model_dir, max_steps=args.max_steps)
+
+
+if __name__ == '__main__':
+  main()

@@ -1,0 +1,83 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/mmt_attn.h declares;
+argument errors are reported through return codes + mmt_last_error (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+  import __graft_entry__  # noqa: F401  (sets sys.path)
+  from mmt_amd import _lib
+  _lib.build()
+  return _lib
+
+
+def test_header_symbols_are_exported(lib):
+  header = open(os.path.join(ROOT, 'include', 'mmt_attn.h')).read()
+  declared = set(re.findall(r'\b(mmt_[a-z_]+)\s*\(', header))
+  assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+  L = lib.lib()
+  for name in declared:
+    assert hasattr(L, name), name
+  assert L.mmt_abi_version() == 1
+  assert int(re.search(r'#define MMT_ABI_VERSION (\d+)', header).group(1)) == 1
+
+
+def test_struct_layout_matches_header(lib):
+  # field order / widths of the ctypes mirrors against the header text
+  header = open(os.path.join(ROOT, 'include', 'mmt_attn.h')).read()
+  body = header[header.index('typedef struct mmt_mask_desc'):header.index('} mmt_mask_desc;')]
+  names = re.findall(r'\b(?:int32_t\*?|const int32_t\*)\s+(\w+);', body)
+  assert names == [f[0] for f in lib.MaskDesc._fields_]
+  body = header[header.index('typedef struct mmt_attn_desc'):header.index('} mmt_attn_desc;')]
+  names = re.findall(r'\b(\w+)(?:\[3\])?;', body)
+  flat = []
+  for line in body.splitlines():
+    m = re.match(r'\s*(?:int32_t|int64_t|float|uint32_t|uint64_t|mmt_mask_desc)\s+([^;]+);', line)
+    if m:
+      flat += [x.strip().split('[')[0] for x in m.group(1).split(',')]
+  assert flat == [f[0] for f in lib.AttnDesc._fields_]
+  assert ctypes.sizeof(lib.MaskDesc) == 8 + 7 * 4 + 4     # pointer + 7 ints, padded to 8
+
+
+def test_argument_errors_without_gpu(lib):
+  L = lib.lib()
+  d = lib.AttnDesc()
+  d.B, d.S, d.N, d.D = 1, 64, 1, 32
+  assert L.mmt_workspace_bytes(d) == 0
+  assert b'head size 64' in L.mmt_last_error()
+  d.D = 64
+  d.dtype = lib.MMT_BF16
+  for arr in (d.q_stride, d.k_stride, d.v_stride, d.o_stride):
+    arr[:] = (64 * 64, 64, 64)
+  d.scale, d.mask_value = 0.125, -10000.0
+  d.mask.local_radius = 8
+  d.mask.n_global, d.mask.global_start = 4, 62            # range leaves the sequence
+  assert L.mmt_attn_fwd(d, 1, 1, 1, None, None, None, None, 1, None, None, 0, None) == -1
+  assert b'global range' in L.mmt_last_error()
+  d.mask.global_start = 10
+  assert L.mmt_workspace_bytes(d) > 0
+  assert L.mmt_attn_fwd(d, None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+  d.q_stride[1] = 60                                       # breaks 16-byte alignment
+  assert L.mmt_attn_fwd(d, 1, 1, 1, None, None, None, None, 1, None, None, 0, None) == -1
+  d.q_stride[1] = 64
+  # a structured call that needs workspace but gets none
+  assert L.mmt_attn_fwd(d, 1, 1, 1, None, None, None, None, 1, None, None, 0, None) == -3
+  assert b'workspace' in L.mmt_last_error()
+  m = lib.MaskDesc()
+  m.id_mode, m.max_dist, m.patches_per_row, m.core_layers = 2, 3, 0, 1
+  assert L.mmt_side_inputs(m, 1, 16, None, None, 0, None, None, None, None) == -1
+  assert b'`num_patch_per_row` must be positive.' in L.mmt_last_error()
+
+
+def test_no_cpu_fallback(lib):
+  import torch
+  import mmt_amd
+  x = torch.zeros(1, 32, 1, 64)
+  with pytest.raises(RuntimeError, match='GPU only'):
+    mmt_amd.relative_attention_forward(x, x, x)

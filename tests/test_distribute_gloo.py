@@ -1,0 +1,65 @@
+"""N>1 path on CPU: world_size-2 gloo run of the bucketed gradient reducer (the same code RCCL
+runs on the GPUs), checked against a single-process computation on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import __graft_entry__  # noqa: F401
+
+
+def _free_port():
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, reduce, out):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  from mmt_amd import distribute
+  strategy = distribute.get_distribution_strategy('mirrored', num_gpus=0, bucket_mb=0.001)
+  assert strategy.num_replicas_in_sync == world and strategy.backend == 'gloo'
+  torch.manual_seed(0)
+  model = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 8),
+                              torch.nn.Linear(8, 1))
+  unused = torch.nn.Parameter(torch.ones(3))           # receives no gradient
+  params = list(model.parameters()) + [unused]
+  reducer = strategy.make_reducer(params, reduce=reduce)
+  assert len(reducer.buckets) > 2                       # several buckets -> overlap path exercised
+  g = torch.Generator().manual_seed(100 + rank)
+  x = torch.randn(4, 16, generator=g)
+  for _ in range(2):                                    # two steps: zero_grad / re-arm
+    reducer.zero_grad()
+    model(x).pow(2).mean().backward()
+    reducer.finish()
+  out[rank] = [p.grad.clone() for p in params]
+  dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('reduce', ['mean', 'sum'])
+def test_bucketed_allreduce_world2(reduce):
+  world = 2
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_worker, args=(world, _free_port(), reduce, out), nprocs=world, join=True)
+  torch.manual_seed(0)
+  model = torch.nn.Sequential(torch.nn.Linear(16, 64), torch.nn.Tanh(), torch.nn.Linear(64, 8),
+                              torch.nn.Linear(8, 1))
+  grads = None
+  for rank in range(world):
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(4, 16, generator=g)
+    model.zero_grad()
+    model(x).pow(2).mean().backward()
+    cur = [p.grad.clone() for p in model.parameters()]
+    grads = cur if grads is None else [a + b for a, b in zip(grads, cur)]
+  if reduce == 'mean':
+    grads = [gr / world for gr in grads]
+  for rank in range(world):
+    got = out[rank]
+    assert float(got[-1].abs().max()) == 0.0            # unused parameter: zero gradient everywhere
+    for a, b in zip(got[:-1], grads):
+      assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
+  for a, b in zip(out[0], out[1]):
+    assert torch.equal(a, b)
