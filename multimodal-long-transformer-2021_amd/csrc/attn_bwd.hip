@@ -13,7 +13,8 @@
 //                         walks query tiles; produces dK, dV.                            [K4b]
 // Global rows (K4a) / global keys (K4b) see the whole sequence: they are split into chunks
 // handled by extra work items of the same launch, summed by small combine kernels.
-// dE / dbias: two-stage tree reduction of dRel^T Q (no atomics, bitwise reproducible).
+// dE / dbias: each K4a wave emits its Q^T.dRel partial (MFMA); one fixed-order pass sums them
+// (no atomics, bitwise reproducible).
 #include "attn_tile.h"
 
 namespace mmt {
@@ -22,8 +23,9 @@ namespace mmt {
 template <typename T, int Rp> struct BwdLds {
   static constexpr int kTab = (32 * kTStride(Rp) * 4 + 15) & ~15;
   static constexpr int kTile = sizeof(T) == 2 ? 32 * 128 : 0;
-  static constexpr int kDq = 2 * kTab + kTile;        // tab, dtab, K/E tile
-  static constexpr int kDkv = kTab + 2 * kTile;       // tab, Q tile, dO tile
+  static constexpr int kBias = Rp * 4;                // bias[id] * tscale
+  static constexpr int kDq = 2 * kTab + kTile + kBias;   // tab, dtab, K/E tile, bias
+  static constexpr int kDkv = kTab + 2 * kTile + kBias;  // tab, Q tile, dO tile, bias
 };
 
 struct TileWalk {
@@ -50,12 +52,10 @@ __device__ __forceinline__ TileWalk band_walk(const PatternDev& pat, int x0, int
   return w;
 }
 
-// Score of one (q,k) pair in the log2 domain + the table column of its relative id.
-// Returns false when the pair does not exist (q or k past the end).
+// Mask bit and relative-table column of one (q,k) pair (col < 0: no relative term).
 template <int MODE, bool GEN, typename P>
-__device__ __forceinline__ bool pair_score(const P& p, int b, int valid_len, int q, int k, float dot,
-                                           const float* trow, float& s2, int& col) {
-  bool keep;
+__device__ __forceinline__ void pair_mask_col(const P& p, int b, int valid_len, int q, int k,
+                                              bool& keep, int& col) {
   int id = -1;
   col = -1;
   if (MODE == kDense) {
@@ -75,11 +75,6 @@ __device__ __forceinline__ bool pair_score(const P& p, int b, int valid_len, int
     keep = (int)seg & ((int)near | (int)is_global(p.pat, k) | (int)is_global(p.pat, q));
     if (p.pat.id_mode == 1) col = min(max(d, -p.pat.m), p.pat.m) + p.pat.m;
   }
-  const float rel = col >= 0 ? trow[col] : 0.f;
-  float s = fmaf(dot, p.sscale, rel);
-  s = keep ? s : s + p.mask_add;
-  s2 = s;
-  return (q < p.S) && (k < p.S);
 }
 
 template <typename T, typename P>
@@ -89,10 +84,18 @@ __device__ __forceinline__ float drop_factor(const P& p, int bn, int q, int k) {
   return hsh >= p.drop_thresh ? p.inv_keep : 0.f;
 }
 
-// Builds T[row][col(id)] = (x_row . E[id] + bias[id]) * tscale for the 32 rows whose fragments
+// bias_ts[id] = bias[id] * tscale, once per wave.
+template <typename T, int Rp, typename P>
+__device__ __forceinline__ void fill_bias(const P& p, int n, float* bias_ts, int lane) {
+  for (int id = lane; id < Rp; id += 64)
+    bias_ts[id] = p.bias ? (float)reinterpret_cast<const T*>(p.bias)[(long)min(id, max(p.R - 1, 0)) * p.N + n] * p.tscale : 0.f;
+}
+
+// Builds T[row][col(id)] = (x_row . E[id]) * tscale + bias_ts[id] for the 32 rows whose fragments
 // are in `xf` (row = lane & 31).
 template <typename T, int Rp, bool IDENT, typename P>
-__device__ __forceinline__ void build_table(const P& p, int n, const Frag<T>& xf, float* tab, int lane) {
+__device__ __forceinline__ void build_table(const P& p, int n, const Frag<T>& xf, float* tab,
+                                            const float* bias_ts, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
 #pragma unroll
@@ -105,10 +108,8 @@ __device__ __forceinline__ void build_table(const P& p, int n, const Frag<T>& xf
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int id = rb * 32 + kap(i, h);
-      float bias = 0.f;
-      if (p.bias) bias = (float)reinterpret_cast<const T*>(p.bias)[(long)min(id, p.R - 1) * p.N + n];
       const int col = IDENT ? id : tcol(p.perm_1d, p.pat.m, id);
-      tab[r * kTStride(Rp) + col] = (c[i] + bias) * p.tscale;
+      tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bias_ts[id]);
     }
   }
 }
@@ -117,7 +118,7 @@ __device__ __forceinline__ void build_table(const P& p, int n, const Frag<T>& xf
 // K4a: dQ, delta, dRel.  Lane (r,h) owns query row q0 + r; registers walk keys.
 // =========================================================================================
 template <typename T, int MODE, int Rp, bool GEN>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
   float* tab = reinterpret_cast<float*>(wl);
   float* dtab = reinterpret_cast<float*>(wl + L::kTab);
   unsigned char* xlds = wl + 2 * L::kTab;
+  float* bias_ts = reinterpret_cast<float*>(wl + 2 * L::kTab + L::kTile);
   constexpr bool IDENT = MODE == kDense || GEN;
 
   const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
@@ -189,38 +191,98 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
   if (!split_item && q_ok && h == 0) p.delta[row_id] = delta;
   const float lse2 = p.lse[row_id] * kLog2e;
 
-  if (p.R > 0) build_table<T, Rp, IDENT>(p, n, qf, tab, lane);
+  fill_bias<T, Rp>(p, n, bias_ts, lane);
   for (int i = lane; i < 32 * kTStride(Rp); i += 64) dtab[i] = 0.f;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (p.R > 0) build_table<T, Rp, IDENT>(p, n, qf, tab, bias_ts, lane);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 
   f32x16 a0 = {0}, a1 = {0};
+  float far_neg = 0.f, far_pos = 0.f;
   const float* trow = tab + r * kTStride(Rp);
   float* dtrow = dtab + r * kTStride(Rp);
   const int n_it = w.count();
-  for (int it = 0; it < n_it; ++it) {
-    const int k0 = w.at(it) * 32;
-    Frag<T> kf, vf;
+  Frag<T> kf, vf;
+  VTile<T> kt;
+  {
+    const int k0 = w.at(0) * 32;
     kf.load_row(K + (unsigned)min(k0 + r, p.S - 1) * ks1, h);
     vf.load_row(V + (unsigned)min(k0 + r, p.S - 1) * vs1, h);
-    VTile<T> kt;
     kt.load(K, ks1, k0, p.S, lane, 0);
+  }
+  for (int it = 0; it < n_it; ++it) {
+    const int k0 = w.at(it) * 32;
     kt.to_lds(xlds, lane);
+    VTile<T> kcur;
+    if constexpr (sizeof(T) == 4) kcur = kt;
     f32x16 c = {0}, dp = {0};
     c = mma_rows(kf, qf, c);     // S^T  [key x q]
     dp = mma_rows(vf, dof, dp);  // dP^T [key x q]
-    float g[16];
+    if (it + 1 < n_it) {         // next tile's operands arrive under this tile's math
+      const int k1 = w.at(it + 1) * 32;
+      kf.load_row(K + (unsigned)min(k1 + r, p.S - 1) * ks1, h);
+      vf.load_row(V + (unsigned)min(k1 + r, p.S - 1) * vs1, h);
+      kt.load(K, ks1, k1, p.S, lane, 0);
+    }
+    // phase 1: mask bits, table columns and the gathered relative scores (reads only)
+    int cols[16];
+    float rel[16];
+    unsigned keepm = 0, existm = 0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int kk = k0 + kap(i, h);
-      float s2; int col;
-      const bool exists = pair_score<MODE, GEN>(p, b, valid_len, q, kk, c[i], trow, s2, col);
-      const float pr = exists ? __builtin_amdgcn_exp2f(s2 - lse2) : 0.f;
-      const float ds = pr * (dp[i] * drop_factor<T>(p, bn, q, kk) - delta);
-      g[i] = ds * p.gscale;
-      if (col >= 0) atomicAdd(&dtrow[col], ds * p.rel_gscale);
+      bool keep;
+      pair_mask_col<MODE, GEN>(p, b, valid_len, q, kk, keep, cols[i]);
+      keepm |= (unsigned)keep << i;
+      existm |= (unsigned)(kk < p.S && q_ok) << i;
+      rel[i] = cols[i] >= 0 ? trow[cols[i]] : 0.f;
     }
-    mma_xt(a0, a1, kt, xlds, g, lane);   // dQ^T[d x q] += K^T[d x key] . dS^T[key x q]
+    // phase 2: P, dS
+    float g[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float s2 = fmaf(c[i], p.sscale, rel[i]);
+      s2 = (keepm >> i) & 1 ? s2 : s2 + p.mask_add;
+      const float pr = (existm >> i) & 1 ? __builtin_amdgcn_exp2f(s2 - lse2) : 0.f;
+      float dpi = dp[i];
+      if (p.drop_thresh) dpi *= drop_factor<T>(p, bn, q, k0 + kap(i, h));
+      g[i] = pr * (dpi - delta);          // dS
+    }
+    // phase 3: dRel scatter.
+    if constexpr (!IDENT) {
+      // permuted 1-D table: column m+d with |d| < m receives exactly ONE key (k = q+d) -> plain
+      // store; the two clipped columns (0 and 2m) are summed in registers.  No atomics.
+      if (p.pat.id_mode == 1) {
+        const int m = p.pat.m, d0 = k0 - q + 4 * h;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int d = d0 + (i & 3) + 8 * (i >> 2);
+          const float x = g[i] * p.rel_gscale;
+          const bool neg = d <= -m, pos = (d >= m) && !neg;
+          far_neg += neg ? x : 0.f;
+          far_pos += pos ? x : 0.f;
+          if (!neg && !pos) dtrow[m + d] = x;
+        }
+      }
+    } else {
+      // arbitrary ids: wave-private LDS float atomics (the two halves share rows)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (cols[i] >= 0) atomicAdd(&dtrow[cols[i]], g[i] * p.rel_gscale);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[i] *= p.gscale;
+    if constexpr (sizeof(T) == 2) mma_xt(a0, a1, kt, xlds, g, lane);   // dQ^T += K^T . dS^T
+    else mma_xt(a0, a1, kcur, xlds, g, lane);
+  }
+  if (!IDENT && p.pat.id_mode == 1) {       // flush the clipped columns (both halves of the row)
+    const float fn = far_neg + half_xchg(far_neg), fp = far_pos + half_xchg(far_pos);
+    if (h == 0) {
+      if (p.pat.m == 0) dtrow[0] = fn + fp;
+      else { dtrow[0] = fn; dtrow[2 * p.pat.m] = fp; }
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -241,10 +303,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
     return;
   }
 
-  // dQ^T += E^T[d x id] . dRel^T[id x q]   (dRel kept at ~16 mantissa bits: hi/lo bf16 split)
   if (p.R > 0) {
+    // (1) this wave's share of dE^T[d x id] = sum_q Q[q][d] * dRel[q][id] and dbias[id] (lane = id).
+    //     Rows of global tokens are excluded here when they are produced by the split items.
+    {
+      VTile<T> qt;
+      qt.load(Q, qs1, q0, p.S, lane, 0);
+      qt.to_lds(xlds, lane);
+      const int widx = (xcd_remap(blockIdx.x, p.n_band_blocks)) * 4 + wave;
+      float* pe = p.part_red + (long)widx * (Rp * 64 + Rp);
+#pragma unroll
+      for (int rb = 0; rb < Rp / 32; ++rb) {
+        const int id = rb * 32 + r;
+        const int col = IDENT ? id : tcol(p.perm_1d, p.pat.m, id);
+        float vals[16], bsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int qq = q0 + kap(i, h);
+          const bool use = id < p.R && qq < p.S && !(p.skip_global && is_global(p.pat, qq));
+          vals[i] = use ? dtab[kap(i, h) * kTStride(Rp) + col] : 0.f;
+          bsum += vals[i];
+        }
+        bsum += half_xchg(bsum);
+        f32x16 e0 = {0}, e1 = {0};
+        mma_xt_hilo(e0, e1, qt, xlds, vals, lane);
+        float* row = pe + (long)id * 64;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          *reinterpret_cast<f32x4*>(row + 8 * gi + 4 * h) = f32x4{e0[4 * gi], e0[4 * gi + 1], e0[4 * gi + 2], e0[4 * gi + 3]};
+          *reinterpret_cast<f32x4*>(row + 32 + 8 * gi + 4 * h) = f32x4{e1[4 * gi], e1[4 * gi + 1], e1[4 * gi + 2], e1[4 * gi + 3]};
+        }
+        if (h == 0) pe[Rp * 64 + id] = bsum;
+      }
+    }
+    // (2) dQ^T += E^T[d x id] . dRel^T[id x q]   (dRel at ~16 mantissa bits: hi/lo bf16 split)
     const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
-    float* dr = p.drel + row_id * Rp;
 #pragma unroll
     for (int rb = 0; rb < Rp / 32; ++rb) {
       float vals[16];
@@ -252,11 +345,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
       for (int i = 0; i < 16; ++i) {
         const int id = rb * 32 + kap(i, h);
         vals[i] = id < p.R ? dtrow[IDENT ? id : tcol(p.perm_1d, p.pat.m, id)] : 0.f;
-      }
-      if (q_ok && !(p.skip_global && is_global(p.pat, q))) {
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi)
-          *reinterpret_cast<f32x4*>(dr + rb * 32 + 8 * gi + 4 * h) = f32x4{vals[4 * gi], vals[4 * gi + 1], vals[4 * gi + 2], vals[4 * gi + 3]};
       }
       VTile<T> et;   // rows = ids rb*32 .. rb*32+31 of E (clamped past R: their dRel is 0)
       et.load(E + (long)(rb * 32) * p.N * 64, (unsigned)(p.N * 64), 0, max(p.R - rb * 32, 1), lane, 0);
@@ -282,25 +370,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const BwdParams p) {
   }
 }
 
-// Global rows: sum the chunk partials, add dRel.E, write dQ / dRel / nothing else.
+// Global rows: sum the chunk partials, add dRel.E, write dQ and the row's dRel (for dE/dbias).
 template <typename T>
 __global__ __launch_bounds__(64) void attn_bwd_dq_combine_kernel(const BwdParams p) {
+  __shared__ float dr_s[64];
   const int bn = blockIdx.y, row = blockIdx.x, d = threadIdx.x;
   const int gblk = row >> 5, rr = row & 31;
   const int b = bn / p.N, n = bn - b * p.N;
   const int q = p.pat.g0 + row;
   const long slot0 = ((long)bn * p.n_gblk + gblk) * p.n_chunks;
-  float acc = 0.f;
-  for (int c = 0; c < p.n_chunks; ++c) acc += p.part_dq[(slot0 + c) * (32 * 64) + rr * 64 + d];
-  const long row_id = ((long)b * p.N + n) * p.S + q;
-  const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
-  for (int id = 0; id < p.R; ++id) {
-    float dr = 0.f;
-    for (int c = 0; c < p.n_chunks; ++c) dr += p.part_dtab[(slot0 + c) * (32 * p.Rp) + rr * p.Rp + id];
-    acc = fmaf(dr, (float)E[(long)id * p.N * 64 + d], acc);
-    if (d == 0) p.drel[row_id * p.Rp + id] = dr;
+  float acc = 0.f, dr = 0.f;
+  for (int c = 0; c < p.n_chunks; ++c) {
+    acc += p.part_dq[(slot0 + c) * (32 * 64) + rr * 64 + d];
+    if (d < p.Rp) dr += p.part_dtab[(slot0 + c) * (32 * p.Rp) + rr * p.Rp + d];
   }
-  if (d == 0) for (int id = p.R; id < p.Rp; ++id) p.drel[row_id * p.Rp + id] = 0.f;
+  if (d >= p.R) dr = 0.f;
+  dr_s[d] = dr;
+  if (d < p.Rp) p.drel[((long)bn * p.pat.ng + row) * p.Rp + d] = dr;
+  __syncthreads();
+  const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
+  for (int id = 0; id < p.R; ++id) acc = fmaf(dr_s[id], (float)E[(long)id * p.N * 64 + d], acc);
   T* DQ = reinterpret_cast<T*>(p.dq) + (long)b * p.qs[0] + (long)q * p.qs[1] + (long)n * p.qs[2];
   DQ[d] = (T)acc;
 }
@@ -309,7 +398,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_combine_kernel(const BwdParams
 // K4b: dK, dV.  Lane (r,h) owns key k0 + r; registers walk query rows.
 // =========================================================================================
 template <typename T, int MODE, int Rp, bool GEN>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkv_kernel(const BwdParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -319,6 +408,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
   float* tab = reinterpret_cast<float*>(wl);
   unsigned char* qlds = wl + L::kTab;
   unsigned char* dolds = qlds + L::kTile;
+  float* bias_ts = reinterpret_cast<float*>(dolds + L::kTile);
   constexpr bool IDENT = MODE == kDense || GEN;
 
   const int n_tiles = (p.S + 31) >> 5, nkb = (p.S + 127) >> 7;
@@ -362,42 +452,72 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const BwdParams p) {
   kf.load_row(K + kc * ks1, h);
   vf.load_row(V + kc * vs1, h);
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  fill_bias<T, Rp>(p, n, bias_ts, lane);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   const int n_it = w.count();
+  VTile<T> qt, dot;
+  if constexpr (sizeof(T) == 2) {            // first tile's rows (prefetch registers)
+    qt.load(Q, qs1, w.at(0) * 32, p.S, lane, 0);
+    dot.load(DO, os1, w.at(0) * 32, p.S, lane, 0);
+  }
   for (int it = 0; it < n_it; ++it) {
     const int q0 = w.at(it) * 32;
     Frag<T> qf, dof;
-    qf.load_row(Q + (unsigned)min(q0 + r, p.S - 1) * qs1, h);
-    dof.load_row(DO + (unsigned)min(q0 + r, p.S - 1) * os1, h);
-    VTile<T> qt, dot;
-    qt.load(Q, qs1, q0, p.S, lane, 0);
-    dot.load(DO, os1, q0, p.S, lane, 0);
-    qt.to_lds(qlds, lane);
-    dot.to_lds(dolds, lane);
-    if (p.R > 0) build_table<T, Rp, IDENT>(p, n, qf, tab, lane);   // T rows = this q tile
+    if constexpr (sizeof(T) == 2) {
+      qt.to_lds(qlds, lane);
+      dot.to_lds(dolds, lane);
+      if (it + 1 < n_it) {                   // next tile's rows arrive under this tile's math
+        qt.load(Q, qs1, w.at(it + 1) * 32, p.S, lane, 0);
+        dot.load(DO, os1, w.at(it + 1) * 32, p.S, lane, 0);
+      }
+    } else {
+      qf.load_row(Q + (unsigned)min(q0 + r, p.S - 1) * qs1, h);
+      dof.load_row(DO + (unsigned)min(q0 + r, p.S - 1) * os1, h);
+      qt.load(Q, qs1, q0, p.S, lane, 0);
+      dot.load(DO, os1, q0, p.S, lane, 0);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if constexpr (sizeof(T) == 2) frag_from_tile(qf, qlds, lane);
+    if (p.R > 0) build_table<T, Rp, IDENT>(p, n, qf, tab, bias_ts, lane);   // T rows = this q tile
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     f32x16 c = {0}, dp = {0};
     c = mma_rows(qf, kf, c);     // S  [q x key]
+    if constexpr (sizeof(T) == 2) frag_from_tile(dof, dolds, lane);
     dp = mma_rows(dof, vf, dp);  // dP [q x key]
+    int cols[16];
+    float rel[16];
+    unsigned keepm = 0, existm = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int qq = q0 + kap(i, h);
+      bool keep;
+      pair_mask_col<MODE, GEN>(p, b, valid_len, qq, k, keep, cols[i]);
+      keepm |= (unsigned)keep << i;
+      existm |= (unsigned)(qq < p.S && k_ok) << i;
+      rel[i] = cols[i] >= 0 ? tab[kap(i, h) * kTStride(Rp) + cols[i]] : 0.f;
+    }
     float pv[16], g[16];
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi) {
-      const int qb = q0 + 8 * gi + 4 * h;      // 4 consecutive query rows
+      // per-row constants (LSE, delta) of 4 consecutive query rows
       float l4[4], d4[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int qq = min(qb + j, p.S - 1);
+        const int qq = min(q0 + 8 * gi + 4 * h + j, p.S - 1);
         l4[j] = lse_bn[qq] * kLog2e;
         d4[j] = delta_bn[qq];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int i = 4 * gi + j, qq = qb + j;
-        float s2; int col;
-        const bool exists = pair_score<MODE, GEN>(p, b, valid_len, qq, k, c[i],
-                                                   tab + (8 * gi + 4 * h + j) * kTStride(Rp), s2, col);
-        const float pr = exists ? __builtin_amdgcn_exp2f(s2 - l4[j]) : 0.f;
-        const float df = drop_factor<T>(p, bn, qq, k);
+        const int i = 4 * gi + j;
+        float s2 = fmaf(c[i], p.sscale, rel[i]);
+        s2 = (keepm >> i) & 1 ? s2 : s2 + p.mask_add;
+        const float pr = (existm >> i) & 1 ? __builtin_amdgcn_exp2f(s2 - l4[j]) : 0.f;
+        float df = 1.f;
+        if (p.drop_thresh) df = drop_factor<T>(p, bn, q0 + kap(i, h), k);
         pv[i] = pr * df;
         g[i] = pr * (dp[i] * df - d4[j]) * p.gscale;
       }
@@ -463,59 +583,47 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_combine_kernel(const BwdParam
 }
 
 // =========================================================================================
-// K4c: dE[id,n,:] = sum_{b,q} dRel[b,n,q,id] * Q[b,q,n,:],  dbias[id,n] = sum dRel.
-// Stage 1: grid (n_split, N), 256 threads; thread t owns id = t / 8 (+32) and 8 head dims.
-// Stage 2: fixed-order sum of the n_split partials.
+// K4c: dE[id,n,:] = sum over the per-wave partials of head n (+ the rows of global tokens),
+// dbias likewise.  Fixed summation order: bitwise reproducible.  grid (Rp, N), 64 threads = d.
 // =========================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void drel_reduce1_kernel(const BwdParams p) {
-  const int n = blockIdx.y, split = blockIdx.x, t = threadIdx.x;
-  const int id0 = t >> 3, d0 = (t & 7) * 8;
-  const long rows = (long)p.B * p.S;
-  const long per = (rows + p.n_split - 1) / p.n_split;
-  const long lo = split * per, hi = min(rows, lo + per);
-  float acc[2][8] = {{0}}, bs[2] = {0.f, 0.f};
-  for (long row = lo; row < hi; ++row) {
-    const int b = (int)(row / p.S), q = (int)(row - (long)b * p.S);
-    const T* qr = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)q * p.qs[1] + (long)n * p.qs[2] + d0;
-    float qv[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qv[j] = (float)qr[j];
-    const float* dr = p.drel + (((long)b * p.N + n) * p.S + q) * p.Rp;
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      if (u * 32 < p.Rp) {
-        const float x = dr[u * 32 + id0];
-        bs[u] += x;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[u][j] = fmaf(x, qv[j], acc[u][j]);
+__global__ __launch_bounds__(1024) void drel_reduce_kernel(const BwdParams p) {
+  __shared__ float red[16][64], redb[16];
+  const int id = blockIdx.x, n = blockIdx.y, d = threadIdx.x & 63, part = threadIdx.x >> 6;
+  if (id >= p.R) return;
+  const int per = p.Rp * 64 + p.Rp;
+  const int waves_per_bn = ((p.S + 127) >> 7) * 4;
+  const int live = (p.S + 31) >> 5;               // waves past the end of the sequence wrote nothing
+  const int total = p.B * live;
+  const int chunk = (total + 15) >> 4;
+  const int lo = part * chunk, hi = min(total, lo + chunk);
+  float acc = 0.f, bs = 0.f;
+#pragma unroll 8
+  for (int i = lo; i < hi; ++i) {
+    const int b = i / live, w = i - b * live;
+    const float* src = p.part_red + ((long)(b * p.N + n) * waves_per_bn + w) * per;
+    acc += src[id * 64 + d];
+    if (d == 0) bs += src[p.Rp * 64 + id];
+  }
+  if (part == 0 && p.n_gblk > 0) {                // rows of global tokens (from the combine kernel)
+    for (int b = 0; b < p.B; ++b) {
+      const float* dr = p.drel + (long)(b * p.N + n) * p.pat.ng * p.Rp;
+      const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)n * p.qs[2];
+      for (int g = 0; g < p.pat.ng; ++g) {
+        const float x = dr[g * p.Rp + id];
+        acc = fmaf(x, (float)Q[(long)(p.pat.g0 + g) * p.qs[1] + d], acc);
+        if (d == 0) bs += x;
       }
     }
   }
-  float* out = p.part_red + ((long)n * p.n_split + split) * (p.Rp * 64 + p.Rp);
-  for (int u = 0; u < 2; ++u) {
-    if (u * 32 < p.Rp) {
-      const int id = u * 32 + id0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) out[id * 64 + d0 + j] = acc[u][j];
-      if ((t & 7) == 0) out[p.Rp * 64 + id] = bs[u];
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void drel_reduce2_kernel(const BwdParams p) {
-  const int n = blockIdx.x;
-  const int per = p.Rp * 64 + p.Rp;
-  for (int i = threadIdx.x; i < per; i += 256) {
-    float acc = 0.f;
-    for (int s = 0; s < p.n_split; ++s) acc += p.part_red[((long)n * p.n_split + s) * per + i];
-    if (i < p.Rp * 64) {
-      const int id = i >> 6, d = i & 63;
-      if (id < p.R) p.drel_emb[((long)id * p.N + n) * 64 + d] = acc;
-    } else {
-      const int id = i - p.Rp * 64;
-      if (id < p.R && p.drel_bias) p.drel_bias[(long)id * p.N + n] = acc;
-    }
+  red[part][d] = acc;
+  if (d == 0) redb[part] = bs;
+  __syncthreads();
+  if (part == 0) {
+    float a = 0.f, bsum = 0.f;
+    for (int j = 0; j < 16; ++j) { a += red[j][d]; bsum += redb[j]; }
+    p.drel_emb[((long)id * p.N + n) * 64 + d] = a;
+    if (d == 0 && p.drel_bias) p.drel_bias[(long)id * p.N + n] = bsum;
   }
 }
 
@@ -547,9 +655,7 @@ static hipError_t launch_bwd_one(const BwdParams& p, hipStream_t st) {
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   if (p.R > 0) {
-    hipLaunchKernelGGL(drel_reduce1_kernel<T>, dim3(p.n_split, p.N), dim3(256), 0, st, p);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(drel_reduce2_kernel, dim3(p.N), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(drel_reduce_kernel<T>, dim3(p.Rp, p.N), dim3(1024), 0, st, p);
     e = hipGetLastError();
   }
   return e;

@@ -54,11 +54,11 @@ struct BwdParams {
   float inv_keep;
   // workspace
   float* delta;      // [B,N,S]       rowsum(dO * O)
-  float* drel;       // [B,N,S,Rp]    d(relall), id order
+  float* drel;       // [B*N, n_global, Rp]  d(relall) rows of the global tokens, id order
   float* part_dq;    // [B*N, n_gblk, n_chunks, 32, 64]   global-row partials
   float* part_dtab;  // [B*N, n_gblk, n_chunks, 32, Rp]
   float* part_dkv;   // [B*N, n_gblk, n_chunks, 2, 32, 64] global-key partials
-  float* part_red;   // [N, n_split, Rp*64 + Rp]           dE / dbias partials
+  float* part_red;   // [B*N * ceil(S/128) * 4 waves, Rp*64 + Rp]  per-wave dE^T / dbias partials
   int n_band_blocks, n_chunks, chunk_tiles, n_gblk, n_split;
 };
 

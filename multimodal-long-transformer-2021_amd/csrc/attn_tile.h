@@ -77,6 +77,15 @@ template <> struct VTile<float> {    // A operand of the 32x32x2 PV product, str
   __device__ __forceinline__ void to_lds(unsigned char*, int) const {}
 };
 
+// Row fragment (MFMA A/B operand, row = lane & 31) read back from a wave-private LDS tile that
+// was written with VTile<__bf16>::to_lds: saves the second, fragment-shaped global load.
+__device__ __forceinline__ void frag_from_tile(Frag<__bf16>& f, const unsigned char* lds, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const unsigned char* row = lds + r * 128 + ((h ^ ((r >> 1) & 1)) << 6);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) f.v[s] = *reinterpret_cast<const bf16x8*>(row + s * 16);
+}
+
 __device__ __forceinline__ float half_xchg(float x) { return __shfl_xor(x, 32, 64); }
 
 constexpr int kTStride(int Rp) { return Rp + 1; }

@@ -89,11 +89,11 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
   pl.n_split = (int)std::min<size_t>(256, ((size_t)d->B * d->S + 255) / 256);
   pl.off_delta = 0;
   pl.off_drel = pl.off_delta + bn * d->S;
-  pl.off_pdq = pl.off_drel + bn * d->S * Rp;
+  pl.off_pdq = pl.off_drel + bn * (size_t)d->mask.n_global * Rp;
   pl.off_pdtab = pl.off_pdq + bn * pl.n_rowblk * pl.n_chunks * (32 * 64);
   pl.off_pdkv = pl.off_pdtab + bn * pl.n_rowblk * pl.n_chunks * (32 * Rp);
   pl.off_red = pl.off_pdkv + bn * pl.n_rowblk * pl.n_chunks * (2 * 32 * 64);
-  pl.bwd_ws = (pl.off_red + (size_t)d->N * pl.n_split * (Rp * 64 + Rp)) * sizeof(float);
+  pl.bwd_ws = (pl.off_red + bn * ((d->S + 127) / 128) * 4 * (Rp * 64 + Rp)) * sizeof(float);
   return pl;
 }
 

@@ -1,0 +1,23 @@
+"""Dev tool: times the attention forward/backward entry points at BASELINE config 3 (not part of the product)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'multimodal-long-transformer-2021_amd'))
+import torch, mmt_amd
+torch.manual_seed(0)
+B, S, N = 4, 4096, 12
+dt = torch.bfloat16
+qkv = torch.randn(B, S, 3, N, 64, device='cuda', dtype=dt)
+q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+emb = (torch.randn(32, N, 64, device='cuda') * 0.02).to(dt); bias = (torch.randn(32, N, device='cuda') * 0.02).to(dt)
+pat = mmt_amd.AttentionPattern(local_radius=64, global_start=3971, n_global=8, id_mode=1, max_dist=12)
+out, lse = mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat)
+dout = torch.randn_like(out)
+def t(fn, n=20):
+  for _ in range(3): fn()
+  torch.cuda.synchronize()
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
+  for _ in range(n): fn()
+  e1.record(); torch.cuda.synchronize()
+  return e0.elapsed_time(e1) / n * 1e3
+print('fwd us', round(t(lambda: mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat)), 1))
+print('bwd us', round(t(lambda: mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, out, lse, pattern=pat)), 1))
