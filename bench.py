@@ -98,7 +98,13 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    # RCCL ("nccl" on ROCm).  MMT_DIST_BACKEND=gloo + MMT_ONE_GPU=1 is a rehearsal mode that runs
+    # several ranks on ONE GPU (the development box has a single device).
+    backend = os.environ.get('MMT_DIST_BACKEND', 'nccl')
+    if os.environ.get('MMT_ONE_GPU'):
+      local_rank = 0
+    kw = {'device_id': torch.device('cuda', local_rank)} if backend == 'nccl' else {}
+    dist.init_process_group(backend, **kw)
   torch.cuda.set_device(local_rank)
   dev = torch.device('cuda', local_rank)
 
@@ -159,8 +165,14 @@ def main():
   flops, byts = attn_algorithmic(cfg, 2)
   gbs = byts * B / (attn_ms * 1e-3) / 1e9
   tfs = flops * B / (attn_ms * 1e-3) / 1e12
+  traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE)
+  try:
+    with open(os.path.join(ROOT, 'profiles', 'attn_fwd_traffic.json')) as f:
+      traffic = json.load(f)['hbm_bytes_per_launch']
+  except (OSError, KeyError, ValueError):
+    pass
   roofline = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-              'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': None,
+              'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
               'kernel': 'attn_fwd (band + global keys/rows), per launch of B=4',
               'launch_us': round(attn_ms * 1e3, 2),
               'algorithmic_bytes_per_launch': byts * B,

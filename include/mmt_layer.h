@@ -1,0 +1,74 @@
+/* mmt_layer.h -- C ABI of the fused residual-block kernels around the attention core
+ * (SURVEY.md 8(f) rank 1).
+ *
+ * They replace the element-wise chain of etcmodel's `ResidualBlock` / `DenseLayers` as
+ * instantiated by `RelativeTransformerLayers` (reference ctor src/modeling/models/mmt_encoder.py:124-135;
+ * math SURVEY.md App. A.3, pre-activation order `y = x + Dropout(inner(LayerNorm(x)))`,
+ * LayerNorm eps 1e-12, tanh-GELU mmt_encoder.py:53-54), i.e. what TF executes as separate
+ * BiasAdd / Dropout / Add / LayerNormalization / Gelu kernels and their gradients.
+ *
+ * Conventions as in mmt_attn.h: device pointers, caller-owned buffers + workspace, caller's
+ * hipStream_t, 0 / negative MMT_E_* return codes, message via mmt_last_error().
+ * Activations are [rows, H] row-major in `dtype` (MMT_F32 | MMT_BF16); parameters (bias, gamma,
+ * beta) and their gradients are fp32 (master weights); mean / rstd are fp32 [rows].
+ * Dropout keeps element (row, col) iff hash(seed, row*H + col) >= p * 2^16 on 16 bits; the
+ * backward regenerates the mask from the same seed (nothing is stored).
+ */
+#ifndef MMT_LAYER_H_
+#define MMT_LAYER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mmt_rows_desc {
+  int64_t rows;        /* B * S                                         */
+  int32_t H;           /* row length; multiple of 8, <= 8192            */
+  int32_t dtype;       /* MMT_F32 | MMT_BF16                            */
+  float eps;           /* LayerNorm epsilon (1e-12 in the reference)    */
+  float dropout_p;     /* hidden_dropout_prob; 0 disables               */
+  uint64_t dropout_seed;
+} mmt_rows_desc;
+
+/* Bytes of scratch the *_bwd entry points need (column-sum partials). */
+size_t mmt_layer_workspace_bytes(const mmt_rows_desc* desc);
+
+/* y = LayerNorm(x) * gamma + beta; mean, rstd saved for the backward. */
+int mmt_ln_fwd(const mmt_rows_desc* desc, const void* x, const float* gamma, const float* beta,
+               void* y, float* mean, float* rstd, void* stream);
+
+/* dx, dgamma[H], dbeta[H] of mmt_ln_fwd (dgamma / dbeta are overwritten). */
+int mmt_ln_bwd(const mmt_rows_desc* desc, const void* dy, const void* x, const float* gamma,
+               const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Residual block tail + next block's LayerNorm:
+ *   x_new = x + Dropout(o + bias);   h = LayerNorm(x_new) * gamma + beta
+ * gamma == NULL: no LayerNorm (h, mean, rstd unused) -- the last block of a pre-activation stack. */
+int mmt_residual_block_fwd(const mmt_rows_desc* desc, const void* o, const float* bias,
+                           const void* x, const float* gamma, const float* beta, void* x_new,
+                           void* h, float* mean, float* rstd, void* stream);
+
+/* Backward: dX = dx_new_in + LayerNormBwd(dh);  dx = dX;  do = DropoutBwd(dX);
+ * dbias[H] = colsum(do), dgamma, dbeta overwritten.  dx_new_in may be NULL (treated as 0);
+ * dh / gamma NULL together when the forward had no LayerNorm. */
+int mmt_residual_block_bwd(const mmt_rows_desc* desc, const void* dx_new_in, const void* dh,
+                           const void* x_new, const float* gamma, const float* mean,
+                           const float* rstd, void* d_o, void* dx, float* dbias, float* dgamma,
+                           float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* y = gelu_tanh(u + bias)   (DenseLayers hidden activation; rows x H with H = intermediate_size) */
+int mmt_bias_gelu_fwd(const mmt_rows_desc* desc, const void* u, const float* bias, void* y,
+                      void* stream);
+
+/* du = dy * gelu_tanh'(u + bias);  dbias[H] = colsum(du) (overwritten). */
+int mmt_bias_gelu_bwd(const mmt_rows_desc* desc, const void* dy, const void* u, const float* bias,
+                      void* du, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMT_LAYER_H_ */

@@ -1,0 +1,490 @@
+// Fused residual-block kernels for gfx950 (C ABI: include/mmt_layer.h).
+//
+// All of them are HBM-bound streaming kernels: 16-byte loads/stores per lane, one wave per
+// row for the LayerNorm-bearing ones (row kept in registers between the statistics pass and
+// the normalisation pass, wave reductions by DPP/shuffle, no LDS in the row loop), per-wave
+// register accumulators for the column sums (dbias / dgamma / dbeta) that are flushed once per
+// block into a partial slab and summed in fixed order by a second tiny kernel (bitwise
+// reproducible, no atomics).
+#include "../../include/mmt_attn.h"
+#include "../../include/mmt_layer.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "mmt_common.h"
+#include "mmt_err.h"
+
+namespace mmt {
+
+// ---- 8-element chunk I/O --------------------------------------------------------------------
+template <typename T> struct Chunk;
+template <> struct Chunk<__bf16> {
+  static __device__ __forceinline__ void load(const __bf16* p, float (&v)[8]) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+  }
+  static __device__ __forceinline__ void store(__bf16* p, float (&v)[8]) {   // rounds v in place
+    bf16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { t[i] = (__bf16)v[i]; v[i] = (float)t[i]; }
+    *reinterpret_cast<bf16x8*>(p) = t;
+  }
+};
+template <> struct Chunk<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[8]) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+  }
+  static __device__ __forceinline__ void store(float* p, float (&v)[8]) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+};
+__device__ __forceinline__ void load_param(const float* p, float (&v)[8]) { Chunk<float>::load(p, v); }
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+  return x;
+}
+
+// 16 random bits per element, one 32-bit mix per element pair (restated in oracle/layer_ops.py).
+__host__ __device__ __forceinline__ uint32_t drop_bits16(uint32_t seed_lo, uint32_t seed_hi, uint64_t idx) {
+  const uint64_t pair = idx >> 1;
+  const uint32_t hsh = mix32((uint32_t)pair * 0x9E3779B9u + mix32((uint32_t)(pair >> 32) ^ seed_hi) + seed_lo);
+  return (idx & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
+}
+
+struct LayerParams {
+  long rows;
+  int H;
+  float eps, inv_keep;
+  uint32_t thresh16, seed_lo, seed_hi;
+  const void *a, *b, *c;          // inputs (meaning per kernel)
+  const float *p0, *p1, *p2;      // fp32 parameters / statistics
+  const float *mean, *rstd;
+  void *o0, *o1;                  // outputs
+  float *s0, *s1;                 // fp32 outputs (mean/rstd)
+  float* part;                    // partial column sums [nblocks][K][H]
+  int nblocks;
+};
+
+// =============================================================================================
+// x_new = x + Dropout(o + bias);  h = LN(x_new)      (RESID)     |    h = LN(x)    (!RESID)
+//   a = o, b = x, p0 = bias, p1 = gamma, p2 = beta, o0 = x_new, o1 = h, s0 = mean, s1 = rstd
+// =============================================================================================
+template <typename T, int NCH, bool RESID, bool HAS_LN>
+__global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const LayerParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = p.H >> 3;
+  const float invH = 1.f / (float)p.H;
+  for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+    float v[NCH][8];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        const long off = row * p.H + c * 8;
+        if (RESID) {
+          float o[8], x[8], bs[8];
+          Chunk<T>::load(reinterpret_cast<const T*>(p.a) + off, o);
+          Chunk<T>::load(reinterpret_cast<const T*>(p.b) + off, x);
+          load_param(p.p0 + c * 8, bs);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float t = o[i] + bs[i];
+            if (p.thresh16) t = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
+            v[j][i] = x[i] + t;
+          }
+          Chunk<T>::store(reinterpret_cast<T*>(p.o0) + off, v[j]);
+        } else {
+          Chunk<T>::load(reinterpret_cast<const T*>(p.b) + off, v[j]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[j][i] = 0.f;
+      }
+    }
+    if (HAS_LN) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[j][i];
+      const float mean = wave_sum(s) * invH;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+        if (lane + 64 * j < nch)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const float d = v[j][i] - mean; q += d * d; }
+      const float rstd = rsqrtf(wave_sum(q) * invH + p.eps);
+      if (lane == 0) { p.s0[row] = mean; p.s1[row] = rstd; }
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nch) {
+          float g[8], bt[8], y[8];
+          load_param(p.p1 + c * 8, g);
+          load_param(p.p2 + c * 8, bt);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) y[i] = (v[j][i] - mean) * rstd * g[i] + bt[i];
+          Chunk<T>::store(reinterpret_cast<T*>(p.o1) + row * p.H + c * 8, y);
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// dX = dx_in + LNbwd(dh);  dx = dX;  do = DropBwd(dX);  partial column sums {dbias, dgamma, dbeta}
+//   a = dx_in (nullable), b = dh, c = x_new (LN input), p1 = gamma, o0 = do, o1 = dx
+// =============================================================================================
+template <typename T, int NCH, bool RESID, bool HAS_LN>
+__global__ __launch_bounds__(256) void resid_ln_bwd_kernel(const LayerParams p) {
+  __shared__ float red[4][64 * NCH * 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = p.H >> 3;
+  const float invH = 1.f / (float)p.H;
+  float acc_b[NCH][8], acc_g[NCH][8], acc_bt[NCH][8];
+  float gam[NCH][8];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { acc_b[j][i] = 0.f; acc_g[j][i] = 0.f; acc_bt[j][i] = 0.f; gam[j][i] = 0.f; }
+    if (HAS_LN && lane + 64 * j < nch) load_param(p.p1 + (lane + 64 * j) * 8, gam[j]);
+  }
+  for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
+    float g[NCH][8], xh[NCH][8], dyh[NCH][8];
+    float mean = 0.f, rstd = 0.f;
+    if (HAS_LN) { mean = p.mean[row]; rstd = p.rstd[row]; }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      const long off = row * p.H + c * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { g[j][i] = 0.f; xh[j][i] = 0.f; dyh[j][i] = 0.f; }
+      if (c < nch) {
+        if (p.a) Chunk<T>::load(reinterpret_cast<const T*>(p.a) + off, g[j]);
+        if (HAS_LN) {
+          float dh[8], x[8];
+          Chunk<T>::load(reinterpret_cast<const T*>(p.b) + off, dh);
+          Chunk<T>::load(reinterpret_cast<const T*>(p.c) + off, x);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            xh[j][i] = (x[i] - mean) * rstd;
+            dyh[j][i] = dh[i] * gam[j][i];
+            s1 += dyh[j][i];
+            s2 += dyh[j][i] * xh[j][i];
+            acc_g[j][i] += dh[i] * xh[j][i];
+            acc_bt[j][i] += dh[i];
+          }
+        }
+      }
+    }
+    if (HAS_LN) {
+      const float c1 = wave_sum(s1) * invH, c2 = wave_sum(s2) * invH;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g[j][i] += rstd * (dyh[j][i] - c1 - xh[j][i] * c2);
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        const long off = row * p.H + c * 8;
+        float dx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dx[i] = g[j][i];
+        Chunk<T>::store(reinterpret_cast<T*>(p.o1) + off, dx);
+        if (RESID) {
+          float d_o[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            float t = g[j][i];
+            if (p.thresh16) t = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
+            d_o[i] = t;
+            acc_b[j][i] += t;
+          }
+          Chunk<T>::store(reinterpret_cast<T*>(p.o0) + off, d_o);
+        }
+      }
+    }
+  }
+  // block-level sums of the three accumulators -> partial slab [block][k][H]
+  constexpr int kSets = (RESID ? 1 : 0) + (HAS_LN ? 2 : 0);
+  int set = 0;
+  auto flush = [&](float (&acc)[NCH][8]) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[wave][(lane + 64 * j) * 8 + i] = acc[j][i];
+    __syncthreads();
+    for (int col = threadIdx.x; col < p.H; col += 256)
+      p.part[((long)blockIdx.x * kSets + set) * p.H + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    ++set;
+  };
+  if (RESID) flush(acc_b);
+  if (HAS_LN) { flush(acc_g); flush(acc_bt); }
+}
+
+// out[j][col] = sum_blocks part[block][j][col]   (fixed order).  Workgroup = 64 columns x 16
+// block groups; every thread sums nblocks/16 partials (unrolled), LDS combines the groups.
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, int nblocks, int ksets, int H,
+                                                             float* o0, float* o1, float* o2) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;
+  const int total = ksets * H;
+  const int per = (nblocks + 15) >> 4;
+  const int lo = grp * per, hi = min(nblocks, lo + per);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (idx < total) {
+    int b = lo;
+    for (; b + 3 < hi; b += 4) {
+      a0 += part[(long)b * total + idx];
+      a1 += part[(long)(b + 1) * total + idx];
+      a2 += part[(long)(b + 2) * total + idx];
+      a3 += part[(long)(b + 3) * total + idx];
+    }
+    for (; b < hi; ++b) a0 += part[(long)b * total + idx];
+  }
+  red[grp][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (grp == 0 && idx < total) {
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) s += red[g][lane];
+    const int set = idx / H, col = idx - set * H;
+    float* dst = set == 0 ? o0 : (set == 1 ? o1 : o2);
+    dst[col] = s;
+  }
+}
+
+// =============================================================================================
+// GELU (tanh approximation, mmt_encoder.py:53-54) with the dense layer's bias folded in.
+// =============================================================================================
+__device__ __forceinline__ float gelu_tanh(float z, float& dz) {
+  const float k = 0.7978845608028654f, c = 0.044715f;
+  const float z2 = z * z;
+  const float inner = k * z * fmaf(c, z2, 1.f);
+  // tanh(a) = 1 - 2 / (1 + 2^(2a*log2e)): v_exp_f32 + v_rcp_f32, saturates cleanly at +-1
+  const float e = __builtin_amdgcn_exp2f(inner * (2.f * kLog2e));
+  const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+  dz = 0.5f * (1.f + t) + 0.5f * z * (1.f - t * t) * k * fmaf(3.f * c, z2, 1.f);
+  return 0.5f * z * (1.f + t);
+}
+
+// thread = one 8-column chunk (blockIdx.x * 256 + tid), rows strided by gridDim.y
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void bias_gelu_kernel(const LayerParams p) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int nch = p.H >> 3;
+  if (c >= nch) return;
+  float bs[8], acc[8];
+  load_param(p.p0 + c * 8, bs);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (long row = blockIdx.y; row < p.rows; row += gridDim.y) {
+    const long off = row * p.H + c * 8;
+    float u[8], y[8];
+    Chunk<T>::load(reinterpret_cast<const T*>(p.a) + off, u);
+    if (BWD) {
+      float dy[8];
+      Chunk<T>::load(reinterpret_cast<const T*>(p.b) + off, dy);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float dz;
+        (void)gelu_tanh(u[i] + bs[i], dz);
+        y[i] = dy[i] * dz;
+        acc[i] += y[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { float dz; y[i] = gelu_tanh(u[i] + bs[i], dz); }
+    }
+    Chunk<T>::store(reinterpret_cast<T*>(p.o0) + off, y);
+  }
+  if (BWD) {
+    float* dst = p.part + (long)blockIdx.y * p.H + c * 8;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  }
+}
+
+}  // namespace mmt
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+namespace {
+
+#define lfail mmt::fail
+
+constexpr int kRowBlocks = 1024;   // blocks of the row-wise kernels (4 rows in flight each)
+constexpr int kGeluRowSplit = 512; // gridDim.y of the GELU kernels
+
+int check_rows(const mmt_rows_desc* d, int max_h) {
+  if (!d) return lfail(MMT_E_INVALID, "desc is NULL");
+  if (d->rows <= 0 || d->H <= 0 || (d->H & 7)) return lfail(MMT_E_INVALID, "rows must be positive and H a positive multiple of 8");
+  if (d->H > max_h) return lfail(MMT_E_UNSUPPORTED, "H=%d exceeds the built maximum %d", d->H, max_h);
+  if (d->dtype != MMT_F32 && d->dtype != MMT_BF16) return lfail(MMT_E_INVALID, "bad dtype %d", d->dtype);
+  if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return lfail(MMT_E_INVALID, "dropout_p must be in [0,1)");
+  return MMT_OK;
+}
+
+int row_blocks(const mmt_rows_desc* d) {
+  const long need = (d->rows + 3) / 4;
+  return (int)(need < kRowBlocks ? need : kRowBlocks);
+}
+
+void fill(mmt::LayerParams& p, const mmt_rows_desc* d) {
+  p = mmt::LayerParams{};
+  p.rows = d->rows; p.H = d->H; p.eps = d->eps;
+  if (d->dropout_p > 0.f) {
+    unsigned t = (unsigned)(d->dropout_p * 65536.0 + 0.5);
+    p.thresh16 = t < 1 ? 1 : (t > 65535 ? 65535 : t);
+    p.inv_keep = 65536.f / (65536.f - (float)p.thresh16);   // exact keep probability of the 16-bit test
+    p.seed_lo = (uint32_t)d->dropout_seed; p.seed_hi = (uint32_t)(d->dropout_seed >> 32);
+  }
+}
+
+template <bool RESID, bool HAS_LN>
+hipError_t launch_fwd(const mmt::LayerParams& p, bool bf16, hipStream_t st, int blocks) {
+  const int nchl = ((p.H >> 3) + 63) / 64;
+#define MMT_FWD(T, N) hipLaunchKernelGGL((mmt::resid_ln_fwd_kernel<T, N, RESID, HAS_LN>), dim3(blocks), dim3(256), 0, st, p)
+  if (bf16) { if (nchl <= 1) MMT_FWD(__bf16, 1); else if (nchl <= 2) MMT_FWD(__bf16, 2); else if (nchl <= 4) MMT_FWD(__bf16, 4); else MMT_FWD(__bf16, 8); }
+  else { if (nchl <= 1) MMT_FWD(float, 1); else if (nchl <= 2) MMT_FWD(float, 2); else if (nchl <= 4) MMT_FWD(float, 4); else MMT_FWD(float, 8); }
+#undef MMT_FWD
+  return hipGetLastError();
+}
+
+template <bool RESID, bool HAS_LN>
+hipError_t launch_bwd(const mmt::LayerParams& p, bool bf16, hipStream_t st, int blocks) {
+  const int nchl = ((p.H >> 3) + 63) / 64;
+#define MMT_BWD(T, N) hipLaunchKernelGGL((mmt::resid_ln_bwd_kernel<T, N, RESID, HAS_LN>), dim3(blocks), dim3(256), 0, st, p)
+  if (bf16) { if (nchl <= 1) MMT_BWD(__bf16, 1); else if (nchl <= 2) MMT_BWD(__bf16, 2); else MMT_BWD(__bf16, 4); }
+  else { if (nchl <= 1) MMT_BWD(float, 1); else if (nchl <= 2) MMT_BWD(float, 2); else MMT_BWD(float, 4); }
+#undef MMT_BWD
+  return hipGetLastError();
+}
+
+constexpr int kMaxLnH = 2048;   // row kept in registers: 4 chunks of 8 per lane
+
+}  // namespace
+
+extern "C" {
+
+size_t mmt_layer_workspace_bytes(const mmt_rows_desc* d) {
+  if (!d || d->H <= 0) return 0;
+  const size_t a = (size_t)kRowBlocks * 3 * d->H * sizeof(float);
+  const size_t b = (size_t)kGeluRowSplit * d->H * sizeof(float);
+  return a > b ? a : b;
+}
+
+int mmt_ln_fwd(const mmt_rows_desc* d, const void* x, const float* gamma, const float* beta,
+               void* y, float* mean, float* rstd, void* stream) {
+  if (int rc = check_rows(d, kMaxLnH)) return rc;
+  if (!x || !gamma || !beta || !y || !mean || !rstd) return lfail(MMT_E_INVALID, "mmt_ln_fwd: NULL argument");
+  mmt::LayerParams p; fill(p, d);
+  p.b = x; p.p1 = gamma; p.p2 = beta; p.o1 = y; p.s0 = mean; p.s1 = rstd;
+  hipError_t e = launch_fwd<false, true>(p, d->dtype == MMT_BF16, (hipStream_t)stream, row_blocks(d));
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_ln_fwd: %s", hipGetErrorString(e));
+}
+
+int mmt_ln_bwd(const mmt_rows_desc* d, const void* dy, const void* x, const float* gamma,
+               const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
+               void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_rows(d, kMaxLnH)) return rc;
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return lfail(MMT_E_INVALID, "mmt_ln_bwd: NULL argument");
+  if (!ws || ws_bytes < mmt_layer_workspace_bytes(d)) return lfail(MMT_E_WORKSPACE, "mmt_ln_bwd: workspace too small");
+  mmt::LayerParams p; fill(p, d);
+  p.b = dy; p.c = x; p.p1 = gamma; p.mean = mean; p.rstd = rstd; p.o1 = dx; p.part = (float*)ws;
+  p.nblocks = row_blocks(d);
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = launch_bwd<false, true>(p, d->dtype == MMT_BF16, st, p.nblocks);
+  if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_ln_bwd: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((2 * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, 2, d->H, dgamma, dbeta, (float*)nullptr);
+  e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_ln_bwd reduce: %s", hipGetErrorString(e));
+}
+
+int mmt_residual_block_fwd(const mmt_rows_desc* d, const void* o, const float* bias, const void* x,
+                           const float* gamma, const float* beta, void* x_new, void* h, float* mean,
+                           float* rstd, void* stream) {
+  if (int rc = check_rows(d, kMaxLnH)) return rc;
+  if (!o || !bias || !x || !x_new) return lfail(MMT_E_INVALID, "mmt_residual_block_fwd: NULL argument");
+  if (gamma && (!beta || !h || !mean || !rstd)) return lfail(MMT_E_INVALID, "mmt_residual_block_fwd: LayerNorm outputs missing");
+  mmt::LayerParams p; fill(p, d);
+  p.a = o; p.b = x; p.p0 = bias; p.p1 = gamma; p.p2 = beta; p.o0 = x_new; p.o1 = h; p.s0 = mean; p.s1 = rstd;
+  const bool bf16 = d->dtype == MMT_BF16;
+  hipError_t e = gamma ? launch_fwd<true, true>(p, bf16, (hipStream_t)stream, row_blocks(d))
+                       : launch_fwd<true, false>(p, bf16, (hipStream_t)stream, row_blocks(d));
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_residual_block_fwd: %s", hipGetErrorString(e));
+}
+
+int mmt_residual_block_bwd(const mmt_rows_desc* d, const void* dx_new_in, const void* dh,
+                           const void* x_new, const float* gamma, const float* mean, const float* rstd,
+                           void* d_o, void* dx, float* dbias, float* dgamma, float* dbeta,
+                           void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_rows(d, kMaxLnH)) return rc;
+  const bool has_ln = gamma != nullptr;
+  if (!d_o || !dx || !dbias) return lfail(MMT_E_INVALID, "mmt_residual_block_bwd: NULL output");
+  if (has_ln && (!dh || !x_new || !mean || !rstd || !dgamma || !dbeta)) return lfail(MMT_E_INVALID, "mmt_residual_block_bwd: LayerNorm arguments missing");
+  if (!has_ln && !dx_new_in) return lfail(MMT_E_INVALID, "mmt_residual_block_bwd: no incoming gradient");
+  if (!ws || ws_bytes < mmt_layer_workspace_bytes(d)) return lfail(MMT_E_WORKSPACE, "mmt_residual_block_bwd: workspace too small");
+  mmt::LayerParams p; fill(p, d);
+  p.a = dx_new_in; p.b = dh; p.c = x_new; p.p1 = gamma; p.mean = mean; p.rstd = rstd; p.o0 = d_o; p.o1 = dx;
+  p.part = (float*)ws; p.nblocks = row_blocks(d);
+  hipStream_t st = (hipStream_t)stream;
+  const bool bf16 = d->dtype == MMT_BF16;
+  hipError_t e = has_ln ? launch_bwd<true, true>(p, bf16, st, p.nblocks) : launch_bwd<true, false>(p, bf16, st, p.nblocks);
+  if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_residual_block_bwd: %s", hipGetErrorString(e));
+  const int ksets = has_ln ? 3 : 1;
+  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((ksets * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, ksets, d->H, dbias, dgamma, dbeta);
+  e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_residual_block_bwd reduce: %s", hipGetErrorString(e));
+}
+
+int mmt_bias_gelu_fwd(const mmt_rows_desc* d, const void* u, const float* bias, void* y, void* stream) {
+  if (int rc = check_rows(d, 8192)) return rc;
+  if (!u || !bias || !y) return lfail(MMT_E_INVALID, "mmt_bias_gelu_fwd: NULL argument");
+  mmt::LayerParams p; fill(p, d);
+  p.a = u; p.p0 = bias; p.o0 = y;
+  const int nch = d->H >> 3;
+  const long gy = d->rows < kGeluRowSplit ? d->rows : kGeluRowSplit;
+  dim3 grid((nch + 255) / 256, (unsigned)gy);
+  if (d->dtype == MMT_BF16) hipLaunchKernelGGL((mmt::bias_gelu_kernel<__bf16, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((mmt::bias_gelu_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_bias_gelu_fwd: %s", hipGetErrorString(e));
+}
+
+int mmt_bias_gelu_bwd(const mmt_rows_desc* d, const void* dy, const void* u, const float* bias, void* du,
+                      float* dbias, void* ws, size_t ws_bytes, void* stream) {
+  if (int rc = check_rows(d, 8192)) return rc;
+  if (!dy || !u || !bias || !du || !dbias) return lfail(MMT_E_INVALID, "mmt_bias_gelu_bwd: NULL argument");
+  if (!ws || ws_bytes < mmt_layer_workspace_bytes(d)) return lfail(MMT_E_WORKSPACE, "mmt_bias_gelu_bwd: workspace too small");
+  mmt::LayerParams p; fill(p, d);
+  p.a = u; p.b = dy; p.p0 = bias; p.o0 = du; p.part = (float*)ws;
+  const int nch = d->H >> 3;
+  const long gy = d->rows < kGeluRowSplit ? d->rows : kGeluRowSplit;
+  dim3 grid((nch + 255) / 256, (unsigned)gy);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == MMT_BF16) hipLaunchKernelGGL((mmt::bias_gelu_kernel<__bf16, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((mmt::bias_gelu_kernel<float, true>), grid, dim3(256), 0, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_bias_gelu_bwd: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((d->H + 63) / 64), dim3(1024), 0, st, p.part, (int)gy, 1, d->H, dbias, (float*)nullptr, (float*)nullptr);
+  e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_bias_gelu_bwd reduce: %s", hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -10,11 +10,13 @@
 #include <cstring>
 
 #include "attn_kernels.h"
+#include "mmt_err.h"
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
+namespace mmt {
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -22,6 +24,10 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+}  // namespace mmt
+
+namespace {
+using mmt::fail;
 
 constexpr int kChunkTiles = 8;  // kRows pass: 8 tiles = 256 keys per partial
 

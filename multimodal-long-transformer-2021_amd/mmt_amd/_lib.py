@@ -19,7 +19,16 @@ MMT_IDS_NONE, MMT_IDS_1D, MMT_IDS_2D = 0, 1, 2
 MMT_FLAG_SCALE_BEFORE_ADD = 1
 
 EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn_fwd',
-           'mmt_attn_bwd', 'mmt_side_inputs')
+           'mmt_attn_bwd', 'mmt_side_inputs',
+           # include/mmt_layer.h
+           'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
+           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd')
+
+
+class RowsDesc(ctypes.Structure):
+  _fields_ = [('rows', ctypes.c_int64), ('H', ctypes.c_int32), ('dtype', ctypes.c_int32),
+              ('eps', ctypes.c_float), ('dropout_p', ctypes.c_float),
+              ('dropout_seed', ctypes.c_uint64)]
 
 
 class MaskDesc(ctypes.Structure):
@@ -87,6 +96,17 @@ def lib() -> ctypes.CDLL:
   L.mmt_side_inputs.restype = ctypes.c_int
   L.mmt_side_inputs.argtypes = [ctypes.POINTER(MaskDesc), ctypes.c_int32, ctypes.c_int32, i32p,
                                 i32p, ctypes.c_int32, i32p, i32p, i32p, vp]
+  rd = ctypes.POINTER(RowsDesc)
+  L.mmt_layer_workspace_bytes.restype = ctypes.c_size_t
+  L.mmt_layer_workspace_bytes.argtypes = [rd]
+  for name, nargs in (('mmt_ln_fwd', 7), ('mmt_ln_bwd', 11), ('mmt_residual_block_fwd', 10),
+                      ('mmt_residual_block_bwd', 14), ('mmt_bias_gelu_fwd', 4), ('mmt_bias_gelu_bwd', 8)):
+    fn = getattr(L, name)
+    fn.restype = ctypes.c_int
+    fn.argtypes = [rd] + [vp] * nargs
+  L.mmt_ln_bwd.argtypes = [rd] + [vp] * 9 + [ctypes.c_size_t, vp]
+  L.mmt_residual_block_bwd.argtypes = [rd] + [vp] * 12 + [ctypes.c_size_t, vp]
+  L.mmt_bias_gelu_bwd.argtypes = [rd] + [vp] * 6 + [ctypes.c_size_t, vp]
   if L.mmt_abi_version() != MMT_ABI_VERSION:
     raise ImportError('libmmt_attn ABI version mismatch')
   _lib = L

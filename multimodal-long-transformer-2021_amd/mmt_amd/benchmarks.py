@@ -23,7 +23,7 @@ def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.
                          'relative_pos_max_distance': cfg['m'], 'local_radius': cfg['radius'],
                          'num_global_tokens': cfg['ng']},
       }})
-  strategy = distribute.DataParallelStrategy('nccl' if world > 1 else None)
+  strategy = distribute.DataParallelStrategy(torch.distributed.get_backend() if world > 1 else None)
   task = tasks.PretrainingTask(exp.task, compute_dtype=dtype, num_replicas=world)
   torch.manual_seed(0)
   model = task.build_model().to(device)

@@ -1,0 +1,180 @@
+"""Fused residual-block ops (C ABI include/mmt_layer.h) as autograd functions.
+
+They replace the BiasAdd / Dropout / Add / LayerNormalization / Gelu chain of etcmodel's
+`ResidualBlock` + `DenseLayers` in the pre-activation order the reference config uses
+(`src/configs/encoders.py:95`; math SURVEY.md App. A.3).  Parameters stay fp32 (master weights)
+and their gradients come back fp32 straight from the kernels.
+"""
+from __future__ import annotations
+
+import itertools
+
+import torch
+
+from . import _lib
+
+_seed_counter = itertools.count(1)
+
+
+def next_seed(base: int = 0) -> int:
+  return (int(base) * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
+
+
+def _desc(x2d: torch.Tensor, eps=1e-12, p=0.0, seed=0) -> _lib.RowsDesc:
+  d = _lib.RowsDesc()
+  d.rows, d.H = x2d.shape[0], x2d.shape[1]
+  if x2d.dtype == torch.float32:
+    d.dtype = _lib.MMT_F32
+  elif x2d.dtype == torch.bfloat16:
+    d.dtype = _lib.MMT_BF16
+  else:
+    raise TypeError(f'fused layer ops support float32 and bfloat16, got {x2d.dtype}')
+  d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), int(seed) & ((1 << 64) - 1)
+  return d
+
+
+def _stream(t):
+  return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ws(desc, like):
+  n = _lib.lib().mmt_layer_workspace_bytes(desc)
+  return torch.empty((max(n, 16),), dtype=torch.uint8, device=like.device)
+
+
+def _check(*ts):
+  for t in ts:
+    if t is not None and not t.is_cuda:
+      raise RuntimeError('fused layer ops run on the GPU only (no CPU fallback)')
+
+
+def _p(t):
+  return None if t is None else t.data_ptr()
+
+
+def _f32(t):
+  return t if t.dtype == torch.float32 and t.is_contiguous() else t.float().contiguous()
+
+
+class _LayerNormFn(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, x, gamma, beta, eps):
+    _check(x, gamma, beta)
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1]).contiguous()
+    gamma, beta = _f32(gamma), _f32(beta)
+    y = torch.empty_like(x2)
+    mean = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    d = _desc(x2, eps)
+    with torch.cuda.device(x.device):
+      _lib.check(_lib.lib().mmt_ln_fwd(d, _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _stream(x)))
+    ctx.save_for_backward(x2, gamma, mean, rstd)
+    ctx.eps, ctx.shape = eps, shape
+    return y.view(shape)
+
+  @staticmethod
+  def backward(ctx, dy):
+    x2, gamma, mean, rstd = ctx.saved_tensors
+    dy2 = dy.reshape(x2.shape).contiguous()
+    dx = torch.empty_like(x2)
+    dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+    d = _desc(x2, ctx.eps)
+    ws = _ws(d, x2)
+    with torch.cuda.device(x2.device):
+      _lib.check(_lib.lib().mmt_ln_bwd(d, _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg),
+                                       _p(db), _p(ws), ws.numel(), _stream(x2)))
+    return dx.view(ctx.shape), dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-12):
+  """LayerNorm over the last dim (gamma/beta fp32)."""
+  return _LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class _ResidualBlockFn(torch.autograd.Function):
+  """(x_new, h) = (x + Dropout(o + bias), LayerNorm(x_new)); h is None without gamma."""
+
+  @staticmethod
+  def forward(ctx, o, bias, x, gamma, beta, eps, p, seed):
+    _check(o, bias, x, gamma, beta)
+    shape = x.shape
+    o2, x2 = o.reshape(-1, shape[-1]).contiguous(), x.reshape(-1, shape[-1]).contiguous()
+    bias = _f32(bias)
+    has_ln = gamma is not None
+    if has_ln:
+      gamma, beta = _f32(gamma), _f32(beta)
+    x_new = torch.empty_like(x2)
+    h = torch.empty_like(x2) if has_ln else None
+    mean = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device) if has_ln else None
+    rstd = torch.empty_like(mean) if has_ln else None
+    d = _desc(x2, eps, p, seed)
+    with torch.cuda.device(x.device):
+      _lib.check(_lib.lib().mmt_residual_block_fwd(d, _p(o2), _p(bias), _p(x2), _p(gamma), _p(beta),
+                                                   _p(x_new), _p(h), _p(mean), _p(rstd), _stream(x)))
+    ctx.save_for_backward(x_new, gamma, mean, rstd, bias)
+    ctx.cfg = (eps, p, seed, shape, has_ln)
+    if has_ln:
+      return x_new.view(shape), h.view(shape)
+    return x_new.view(shape), None
+
+  @staticmethod
+  def backward(ctx, dx_new, dh):
+    x_new, gamma, mean, rstd, bias = ctx.saved_tensors
+    eps, p, seed, shape, has_ln = ctx.cfg
+    dxn = None if dx_new is None else dx_new.reshape(x_new.shape).contiguous()
+    dh2 = None if (dh is None or not has_ln) else dh.reshape(x_new.shape).contiguous()
+    if has_ln and dh2 is None:
+      dh2 = torch.zeros_like(x_new)
+    d_o, dx = torch.empty_like(x_new), torch.empty_like(x_new)
+    dbias = torch.empty_like(bias)
+    dg = torch.empty_like(gamma) if has_ln else None
+    db = torch.empty_like(gamma) if has_ln else None
+    d = _desc(x_new, eps, p, seed)
+    ws = _ws(d, x_new)
+    with torch.cuda.device(x_new.device):
+      _lib.check(_lib.lib().mmt_residual_block_bwd(
+          d, _p(dxn), _p(dh2), _p(x_new), _p(gamma), _p(mean), _p(rstd), _p(d_o), _p(dx), _p(dbias),
+          _p(dg), _p(db), _p(ws), ws.numel(), _stream(x_new)))
+    return d_o.view(shape), dbias, dx.view(shape), dg, db, None, None, None
+
+
+def residual_block(o, bias, x, gamma=None, beta=None, eps=1e-12, p=0.0, seed=0):
+  """x_new = x + Dropout(o + bias); h = LayerNorm(x_new) (None if gamma is None)."""
+  return _ResidualBlockFn.apply(o, bias, x, gamma, beta, eps, p, seed)
+
+
+class _BiasGeluFn(torch.autograd.Function):
+
+  @staticmethod
+  def forward(ctx, u, bias):
+    _check(u, bias)
+    shape = u.shape
+    u2 = u.reshape(-1, shape[-1]).contiguous()
+    bias = _f32(bias)
+    y = torch.empty_like(u2)
+    d = _desc(u2)
+    with torch.cuda.device(u.device):
+      _lib.check(_lib.lib().mmt_bias_gelu_fwd(d, _p(u2), _p(bias), _p(y), _stream(u)))
+    ctx.save_for_backward(u2, bias)
+    ctx.shape = shape
+    return y.view(shape)
+
+  @staticmethod
+  def backward(ctx, dy):
+    u2, bias = ctx.saved_tensors
+    dy2 = dy.reshape(u2.shape).contiguous()
+    du = torch.empty_like(u2)
+    dbias = torch.empty_like(bias)
+    d = _desc(u2)
+    ws = _ws(d, u2)
+    with torch.cuda.device(u2.device):
+      _lib.check(_lib.lib().mmt_bias_gelu_bwd(d, _p(dy2), _p(u2), _p(bias), _p(du), _p(dbias), _p(ws),
+                                              ws.numel(), _stream(u2)))
+    return du.view(ctx.shape), dbias
+
+
+def bias_gelu(u, bias):
+  """gelu_tanh(u + bias)."""
+  return _BiasGeluFn.apply(u, bias)

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+from . import fused, ops
 
 
 def truncated_normal_(t: torch.Tensor, stddev: float) -> torch.Tensor:
@@ -23,12 +23,16 @@ def truncated_normal_(t: torch.Tensor, stddev: float) -> torch.Tensor:
   return nn.init.trunc_normal_(t, mean=0.0, std=stddev, a=-2 * stddev, b=2 * stddev)
 
 
+def _GELU_TANH(x):
+  return F.gelu(x, approximate='tanh')
+
+
 def get_activation(name_or_fn) -> Optional[Callable]:
   """'gelu' is the tanh approximation, as in the reference encoder
   (`mmt_encoder.py:53-54`; TFM `tf_utils.get_activation('gelu')` is also approximate)."""
   if name_or_fn is None or callable(name_or_fn):
     return name_or_fn
-  table = {'gelu': lambda x: F.gelu(x, approximate='tanh'), 'relu': F.relu, 'tanh': torch.tanh,
+  table = {'gelu': _GELU_TANH, 'relu': F.relu, 'tanh': torch.tanh,
            'linear': None, 'identity': None}
   if name_or_fn not in table:
     raise ValueError(f'unknown activation {name_or_fn!r}')
@@ -100,7 +104,7 @@ class RelativeAttention(nn.Module):
     self._calls = 0
 
   def forward(self, x, att_mask=None, relative_att_ids=None, pattern=None, valid_len=None,
-              training=False, dropout_seed=0):
+              training=False, dropout_seed=0, add_output_bias=True):
     B, S, H = x.shape
     qkv = _linear(x, self.qkv_weight, self.qkv_bias).view(B, S, 3, self.num_heads, self.head_size)
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
@@ -114,7 +118,7 @@ class RelativeAttention(nn.Module):
         q, k, v, emb, bias, att_mask=att_mask, relative_att_ids=relative_att_ids, pattern=pattern,
         valid_len=valid_len, dropout_p=p_drop,
         dropout_seed=(int(dropout_seed) * 1000003 + self._calls) if p_drop > 0 else 0)
-    return _linear(out.reshape(B, S, H), self.output_weight, self.output_bias)
+    return _linear(out.reshape(B, S, H), self.output_weight, self.output_bias if add_output_bias else None)
 
 
 class RelativeTransformerLayer(nn.Module):
@@ -170,15 +174,50 @@ class RelativeTransformerLayers(nn.Module):
     super().__init__()
     intermediate_size = intermediate_size or 4 * hidden_size
     self.use_one_hot_lookup = use_one_hot_lookup
+    self.use_fused_kernels = True
     self.layers = nn.ModuleList([
         RelativeTransformerLayer(hidden_size, num_attention_heads, intermediate_size, hidden_act,
                                  hidden_dropout_prob, attention_probs_dropout_prob,
                                  initializer_range, relative_vocab_size, use_pre_activation_order)
         for _ in range(num_hidden_layers)])
 
+  def _fused_ok(self, x):
+    l0 = self.layers[0] if len(self.layers) else None
+    return (l0 is not None and x.is_cuda and l0.use_pre_activation_order and l0.activation is _GELU_TANH
+            and x.dtype in (torch.float32, torch.bfloat16) and x.shape[-1] % 8 == 0 and x.shape[-1] <= 2048
+            and l0.intermediate_weight.shape[0] % 8 == 0 and l0.intermediate_weight.shape[0] <= 8192)
+
+  def _forward_fused(self, x, training, dropout_seed, att_kw):
+    """Pre-activation stack with the fused HIP residual-block kernels: per layer two
+    `residual_block` calls (bias + dropout + residual + the NEXT LayerNorm) and one `bias_gelu`;
+    the GEMMs run without bias epilogues."""
+    L = len(self.layers)
+    p = self.layers[0].hidden_dropout_prob if training else 0.0
+    first = self.layers[0].attention_layer_norm
+    h = fused.layer_norm(x, first.weight, first.bias, first.eps)
+    for i, layer in enumerate(self.layers):
+      o = layer.attention(h, training=training, dropout_seed=dropout_seed * 131 + i,
+                          add_output_bias=False, **att_kw)
+      ln2 = layer.ffn_layer_norm
+      x, h2 = fused.residual_block(o, layer.attention.output_bias, x, ln2.weight, ln2.bias, ln2.eps,
+                                   p, fused.next_seed(dropout_seed) if p else 0)
+      u = _linear(h2, layer.intermediate_weight, None)
+      y = fused.bias_gelu(u, layer.intermediate_bias)
+      f = _linear(y, layer.ffn_output_weight, None)
+      nxt = self.layers[i + 1].attention_layer_norm if i + 1 < L else None
+      x, h = fused.residual_block(f, layer.ffn_output_bias, x,
+                                  None if nxt is None else nxt.weight, None if nxt is None else nxt.bias,
+                                  1e-12 if nxt is None else nxt.eps, p,
+                                  fused.next_seed(dropout_seed) if p else 0)
+    return x
+
   def forward(self, inputs, att_mask=None, relative_att_ids=None, training=False, pattern=None,
               valid_len=None, dropout_seed=0):
     x = inputs
+    if self.use_fused_kernels and self._fused_ok(x):
+      return self._forward_fused(x, training, dropout_seed,
+                                 dict(att_mask=att_mask, relative_att_ids=relative_att_ids,
+                                      pattern=pattern, valid_len=valid_len))
     for i, layer in enumerate(self.layers):
       x = layer(x, training=training, att_mask=att_mask, relative_att_ids=relative_att_ids,
                 pattern=pattern, valid_len=valid_len, dropout_seed=dropout_seed * 131 + i)

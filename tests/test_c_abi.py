@@ -19,7 +19,8 @@ def lib():
 
 def test_header_symbols_are_exported(lib):
   header = open(os.path.join(ROOT, 'include', 'mmt_attn.h')).read()
-  declared = set(re.findall(r'\b(mmt_[a-z_]+)\s*\(', header))
+  layer_header = open(os.path.join(ROOT, 'include', 'mmt_layer.h')).read()
+  declared = set(re.findall(r'\b(mmt_[a-z_]+)\s*\(', header + layer_header))
   assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
   L = lib.lib()
   for name in declared:

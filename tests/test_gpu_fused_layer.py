@@ -1,0 +1,116 @@
+"""Fused residual-block kernels (include/mmt_layer.h) vs the numpy oracle.
+
+fp32: 1e-4 abs on O(1) values (north_star bar is 1e-3); bf16: compared on bf16-rounded inputs
+with 3e-2 (one bf16 rounding of O(1..4) outputs).  The dropout keep mask must match the oracle's
+restatement of the counter hash exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import layer_ops as lo
+from tests._cases import bf16_round
+
+pytestmark = pytest.mark.gpu
+
+DT = [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)]
+
+
+def _mk(rows, H, seed, dtype):
+  rng = np.random.default_rng(seed)
+  a = lambda *s: rng.standard_normal(s).astype(np.float32)
+  o, x, dxn, dh = a(rows, H), a(rows, H), a(rows, H), a(rows, H)
+  bias, gamma, beta = a(H) * 0.1, 1 + 0.1 * a(H), 0.1 * a(H)
+  if dtype == torch.bfloat16:
+    o, x, dxn, dh = (bf16_round(t) for t in (o, x, dxn, dh))
+  return o, x, dxn, dh, bias, gamma, beta
+
+
+def _dev(t, dtype=None):
+  out = torch.from_numpy(np.ascontiguousarray(t)).cuda()
+  return out if dtype is None else out.to(dtype)
+
+
+@pytest.mark.parametrize('dtype,tol', DT, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('rows,H', [(37, 128), (64, 768), (5, 1024), (300, 2048), (16, 8)])
+@pytest.mark.parametrize('p', [0.0, 0.1])
+@pytest.mark.parametrize('has_ln', [True, False])
+def test_residual_block(rows, H, p, has_ln, dtype, tol):
+  from mmt_amd import fused
+  o, x, dxn, dh, bias, gamma, beta = _mk(rows, H, rows + H, dtype)
+  seed = 0x1234_5678_9ABC + rows
+  keep, inv_keep = lo.dropout_keep_mask(rows, H, p, seed) if p else (None, 1.0)
+  to, tx = _dev(o, dtype).requires_grad_(True), _dev(x, dtype).requires_grad_(True)
+  tb = _dev(bias).requires_grad_(True)
+  tg = _dev(gamma).requires_grad_(True) if has_ln else None
+  tbt = _dev(beta).requires_grad_(True) if has_ln else None
+  x_new, h = fused.residual_block(to, tb, tx, tg, tbt, 1e-12, p, seed)
+  want_x, want_h = lo.residual_block_fwd(o, bias, x, gamma if has_ln else None, beta, keep, inv_keep)
+  if p:   # exact mask check: dropped positions are exactly x
+    got_keep = (x_new.detach().float().cpu().numpy() != _dev(x, dtype).float().cpu().numpy())
+    assert not (got_keep & ~keep).any()         # a dropped position is never modified
+    assert (got_keep == keep).mean() > 0.99     # kept positions may round back to x in bf16
+    assert abs(keep.mean() - (1 - p)) < 0.02 + 2.0 / np.sqrt(rows * H)
+  assert np.abs(x_new.detach().float().cpu().numpy() - want_x).max() < tol
+  loss_terms = [(x_new, _dev(dxn, dtype))]
+  if has_ln:
+    xn_for_ln = x_new.detach().float().cpu().numpy().astype(np.float64)    # LN sees the stored (rounded) x_new
+    want_h = lo.layer_norm(xn_for_ln, gamma, beta)[0]
+    assert np.abs(h.detach().float().cpu().numpy() - want_h).max() < tol
+    loss_terms.append((h, _dev(dh, dtype)))
+  sum((a.float() * b.float()).sum() for a, b in loss_terms).backward()
+  w_do, w_dx, w_db, w_dg, w_dbt = lo.residual_block_bwd(
+      dxn.astype(np.float64), dh.astype(np.float64) if has_ln else None,
+      x_new.detach().float().cpu().numpy().astype(np.float64), gamma if has_ln else None, keep, inv_keep)
+  scale = lambda w: max(1.0, np.abs(w).max())
+  assert np.abs(to.grad.float().cpu().numpy() - w_do).max() / scale(w_do) < tol
+  assert np.abs(tx.grad.float().cpu().numpy() - w_dx).max() / scale(w_dx) < tol
+  assert np.abs(tb.grad.cpu().numpy() - w_db).max() / scale(w_db) < tol
+  if has_ln:
+    assert np.abs(tg.grad.cpu().numpy() - w_dg).max() / scale(w_dg) < tol
+    assert np.abs(tbt.grad.cpu().numpy() - w_dbt).max() / scale(w_dbt) < tol
+
+
+@pytest.mark.parametrize('dtype,tol', DT, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('rows,H', [(33, 128), (7, 768), (1024, 768)])
+def test_layer_norm(rows, H, dtype, tol):
+  from mmt_amd import fused
+  _, x, _, dy, _, gamma, beta = _mk(rows, H, 3 * rows + H, dtype)
+  tx = _dev(x, dtype).requires_grad_(True)
+  tg, tb = _dev(gamma).requires_grad_(True), _dev(beta).requires_grad_(True)
+  y = fused.layer_norm(tx, tg, tb, 1e-12)
+  assert np.abs(y.detach().float().cpu().numpy() - lo.layer_norm(x.astype(np.float64), gamma, beta)[0]).max() < tol
+  y.backward(_dev(dy, dtype))
+  dx, dg, db = lo.layer_norm_bwd(dy.astype(np.float64), x.astype(np.float64), gamma)
+  assert np.abs(tx.grad.float().cpu().numpy() - dx).max() < tol * max(1, np.abs(dx).max())
+  assert np.abs(tg.grad.cpu().numpy() - dg).max() < tol * max(1, np.abs(dg).max())
+  assert np.abs(tb.grad.cpu().numpy() - db).max() < tol * max(1, np.abs(db).max())
+
+
+@pytest.mark.parametrize('dtype,tol', DT, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('rows,H', [(33, 512), (600, 3072), (3, 8)])
+def test_bias_gelu(rows, H, dtype, tol):
+  from mmt_amd import fused
+  rng = np.random.default_rng(rows)
+  u = (rng.standard_normal((rows, H)) * 2).astype(np.float32); dy = rng.standard_normal((rows, H)).astype(np.float32)
+  bias = (rng.standard_normal(H) * 0.5).astype(np.float32)
+  if dtype == torch.bfloat16:
+    u, dy = bf16_round(u), bf16_round(dy)
+  tu, tb = _dev(u, dtype).requires_grad_(True), _dev(bias).requires_grad_(True)
+  y = fused.bias_gelu(tu, tb)
+  z = u.astype(np.float64) + bias
+  ref = lo.gelu_tanh(z)
+  assert (np.abs(y.detach().float().cpu().numpy() - ref) / np.maximum(1.0, np.abs(ref))).max() < tol
+  y.backward(_dev(dy, dtype))
+  du = dy * lo.gelu_tanh_grad(z)
+  assert (np.abs(tu.grad.float().cpu().numpy() - du) / np.maximum(1.0, np.abs(du))).max() < tol
+  assert np.abs(tb.grad.cpu().numpy() - du.sum(0)).max() < tol * max(1.0, np.abs(du.sum(0)).max())
+
+
+def test_errors():
+  from mmt_amd import fused
+  from mmt_amd._lib import MmtError
+  x = torch.zeros(4, 12, device='cuda')            # H not a multiple of 8
+  with pytest.raises(MmtError):
+    fused.layer_norm(x, torch.ones(12, device='cuda'), torch.zeros(12, device='cuda'))
+  with pytest.raises(RuntimeError, match='GPU only'):
+    fused.layer_norm(torch.zeros(4, 16), torch.ones(16), torch.zeros(16))
