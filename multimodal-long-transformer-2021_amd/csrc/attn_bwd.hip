@@ -80,8 +80,8 @@ __device__ __forceinline__ void pair_mask_col(const P& p, int b, int valid_len, 
 template <typename T, typename P>
 __device__ __forceinline__ float drop_factor(const P& p, int bn, int q, int k) {
   if (!p.drop_thresh) return 1.f;
-  const uint32_t hsh = dropout_hash(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q, (uint32_t)k);
-  return hsh >= p.drop_thresh ? p.inv_keep : 0.f;
+  const uint32_t bits = drop_bits16(drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q), (uint32_t)k);
+  return bits >= p.drop_thresh ? p.inv_keep : 0.f;
 }
 
 // bias_ts[id] = bias[id] * tscale, once per wave.

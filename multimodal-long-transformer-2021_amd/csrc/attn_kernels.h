@@ -21,7 +21,7 @@ struct FwdParams {
   PatternDev pat;
   int skip_global_rows;  // kBand: rows of global tokens are produced by the kRows pass
   // dropout
-  uint32_t drop_thresh;  // keep iff hash >= thresh; 0 disables
+  uint32_t drop_thresh;  // 16-bit threshold: keep iff bits16 >= thresh; 0 disables
   uint32_t seed_lo, seed_hi;
   float inv_keep;
   // kRows
@@ -34,6 +34,7 @@ struct FwdParams {
 
 hipError_t launch_attn_fwd(const FwdParams& p, int mode, bool bf16, hipStream_t st);
 hipError_t launch_rows_combine(const FwdParams& p, bool bf16, hipStream_t st);
+hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st);   // attn_fwd_band.hip
 
 struct BwdParams {
   const void *q, *k, *v, *emb, *bias, *out, *dout;

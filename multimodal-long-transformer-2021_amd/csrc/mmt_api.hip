@@ -116,10 +116,9 @@ void fill_common(mmt::FwdParams& p, const mmt_attn_desc* d) {
   p.pat = make_pattern(d->mask, d->S);
   p.valid_len = d->mask.valid_len;
   if (d->dropout_p > 0.f) {
-    double t = (double)d->dropout_p * 4294967296.0;
-    p.drop_thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
-    if (p.drop_thresh == 0) p.drop_thresh = 1;
-    p.inv_keep = 1.f / (1.f - d->dropout_p);
+    unsigned t = (unsigned)((double)d->dropout_p * 65536.0 + 0.5);
+    p.drop_thresh = t < 1 ? 1 : (t > 65535 ? 65535 : t);
+    p.inv_keep = 65536.f / (65536.f - (float)p.drop_thresh);   // exact keep probability of the 16-bit test
     p.seed_lo = (uint32_t)d->dropout_seed;
     p.seed_hi = (uint32_t)(d->dropout_seed >> 32);
   }
@@ -173,7 +172,8 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     p.part_o = reinterpret_cast<float*>(workspace);
     p.part_ml = p.part_o + (size_t)desc->B * desc->N * pl.n_rowblk * pl.n_chunks * (32 * 64);
   }
-  e = mmt::launch_attn_fwd(p, mmt::kBand, bf16, st);
+  const bool lean = bf16 && (p.pat.id_mode == 0 || p.perm_1d);   // attn_fwd_band.hip
+  e = lean ? mmt::launch_attn_fwd_band_bf16(p, st) : mmt::launch_attn_fwd(p, mmt::kBand, bf16, st);
   if (e != hipSuccess) return fail(MMT_E_LAUNCH, "band forward launch: %s", hipGetErrorString(e));
   if (pl.split_rows) {
     e = mmt::launch_rows_combine(p, bf16, st);

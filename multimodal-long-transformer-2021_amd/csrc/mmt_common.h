@@ -96,11 +96,18 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-__host__ __device__ __forceinline__ uint32_t dropout_hash(uint32_t seed_lo, uint32_t seed_hi,
-                                                          uint32_t bn, uint32_t q, uint32_t k) {
-  uint32_t a = mix32(seed_lo ^ (bn * 0x9E3779B9u));
-  uint32_t b = mix32(seed_hi + q * 0x85EBCA6Bu + a);
-  return mix32(b ^ (k * 0xC2B2AE35u));
+// Attention-probability dropout: 16 random bits per (b*N+n, q, k); one 32-bit mix serves the
+// key pair (k & ~1, k | 1).  keep iff bits >= thresh16.
+__host__ __device__ __forceinline__ uint32_t drop_row_base(uint32_t seed_lo, uint32_t seed_hi,
+                                                           uint32_t bn, uint32_t q) {
+  return mix32(seed_lo ^ (bn * 0x9E3779B9u)) + seed_hi + q * 0x85EBCA6Bu;
+}
+__host__ __device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row_base, uint32_t k) {
+  return mix32(row_base ^ ((k >> 1) * 0xC2B2AE35u));
+}
+__host__ __device__ __forceinline__ uint32_t drop_bits16(uint32_t row_base, uint32_t k) {
+  const uint32_t hsh = drop_pair_hash(row_base, k);
+  return (k & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
 }
 
 // XCD-aware remap of a 1-D grid: consecutive logical ids land on the same XCD (blocks are
