@@ -674,7 +674,26 @@ static hipError_t launch_bwd_t(const BwdParams& p, int mode, hipStream_t st) {
   return gen ? launch_bwd_rp<T, kBand, true>(p, st) : launch_bwd_rp<T, kBand, false>(p, st);
 }
 
+hipError_t launch_bwd_dq_combine(const BwdParams& p, bool bf16, hipStream_t st) {
+  dim3 grid(p.pat.ng, p.B * p.N);
+  if (bf16) hipLaunchKernelGGL(attn_bwd_dq_combine_kernel<__bf16>, grid, dim3(64), 0, st, p);
+  else hipLaunchKernelGGL(attn_bwd_dq_combine_kernel<float>, grid, dim3(64), 0, st, p);
+  return hipGetLastError();
+}
+hipError_t launch_bwd_dkv_combine(const BwdParams& p, bool bf16, hipStream_t st) {
+  dim3 grid(p.pat.ng, p.B * p.N);
+  if (bf16) hipLaunchKernelGGL(attn_bwd_dkv_combine_kernel<__bf16>, grid, dim3(64), 0, st, p);
+  else hipLaunchKernelGGL(attn_bwd_dkv_combine_kernel<float>, grid, dim3(64), 0, st, p);
+  return hipGetLastError();
+}
+hipError_t launch_drel_reduce(const BwdParams& p, bool bf16, hipStream_t st) {
+  if (bf16) hipLaunchKernelGGL(drel_reduce_kernel<__bf16>, dim3(p.Rp, p.N), dim3(1024), 0, st, p);
+  else hipLaunchKernelGGL(drel_reduce_kernel<float>, dim3(p.Rp, p.N), dim3(1024), 0, st, p);
+  return hipGetLastError();
+}
+
 hipError_t launch_attn_bwd(const BwdParams& p, int mode, bool bf16, hipStream_t st) {
+  if (mode == kBand && bf16 && (p.pat.id_mode == 0 || p.perm_1d)) return launch_attn_bwd_band_bf16(p, st);
   return bf16 ? launch_bwd_t<__bf16>(p, mode, st) : launch_bwd_t<float>(p, mode, st);
 }
 

@@ -1,0 +1,611 @@
+// VALU-lean backward kernels for the common case (bf16, band + global pattern, relative ids
+// none or 1-D with the permuted table).  Same math, work items, workspace layout and outputs as
+// attn_bwd_dq_kernel / attn_bwd_dkv_kernel<kBand> (attn_bwd.hip, which stays the general path:
+// fp32, 2-D ids, dense inputs); see attn_fwd_band.hip for the tile classes.  Differences:
+//   * P needs no running maximum (LSE is known): p = exp2(fma(c, s, rel - lse)) in class A;
+//   * gscale / rel_gscale are folded into the epilogues, not applied per element;
+//   * dRel: clipped columns accumulate in two registers, near columns are plain stores;
+//   * row fragments of a tile that is staged in LDS anyway are read back from LDS
+//     (frag_from_tile) instead of being loaded a second time in fragment shape.
+#include "attn_lean.h"
+
+namespace mmt {
+
+template <int Rp> struct LeanLds {
+  static constexpr int kTab = (32 * kTStride(Rp) * 4 + 15) & ~15;
+  static constexpr int kTile = 32 * 128;
+  static constexpr int kDq = 2 * kTab + kTile;            // T, dT, K/Q/E tile (bias row aliases the tile)
+  static constexpr int kDkv = kTab + 2 * kTile + Rp * 4 + 256;  // T, Q tile, dO tile, bias row, lse2/delta rows
+};
+
+__device__ __forceinline__ void tile_to_lds(unsigned char* lds, const bf16x8 (&v)[4], int lane) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int ci = lane + 64 * u, row = ci >> 3, ch = ci & 7;
+    *reinterpret_cast<bf16x8*>(lds + row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16) = v[u];
+  }
+}
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// =========================================================================================
+// dQ, delta, dRel (lane = query row).
+// =========================================================================================
+template <int Rp, bool HAS_REL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const BwdParams p) {
+  using T = __bf16;
+  using L = LeanLds<Rp>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  unsigned char* wl = smem + wave * L::kDq;
+  float* tab = reinterpret_cast<float*>(wl);
+  float* dtab = reinterpret_cast<float*>(wl + L::kTab);
+  unsigned char* xlds = wl + 2 * L::kTab;
+
+  const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
+  const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
+  const int n_split_blocks = per_bn * p.B * p.N;          // long items first
+  const bool split_item = (int)blockIdx.x < n_split_blocks;
+  int bn, q0, chunk = 0, gblk = 0, band_wg = 0;
+  if (split_item) {
+    bn = blockIdx.x / per_bn;
+    const int item = (blockIdx.x - bn * per_bn) * 4 + wave;
+    if (item >= p.n_chunks * p.n_gblk) return;
+    gblk = item / p.n_chunks;
+    chunk = item - gblk * p.n_chunks;
+    q0 = p.pat.g0 + gblk * 32;
+  } else {
+    band_wg = xcd_remap(blockIdx.x - n_split_blocks, p.n_band_blocks);
+    bn = band_wg / nqb;
+    q0 = (band_wg - bn * nqb) * 128 + wave * 32;
+    if (q0 >= p.S) return;
+  }
+  const int b = bn / p.N, n = bn - b * p.N;
+  const int q = q0 + r;
+  const bool q_ok = q < p.S;
+  const int valid_len = p.valid_len ? p.valid_len[b] : p.S;
+  const int W = p.pat.radius, m = p.pat.m;
+  const bool ignore_band = split_item;
+
+  const unsigned qs1b = (unsigned)p.qs[1] * 2, ks1b = (unsigned)p.ks[1] * 2, vs1b = (unsigned)p.vs[1] * 2, os1b = (unsigned)p.os[1] * 2;
+  const T* Qb = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)n * p.qs[2];
+  const T* Kb = reinterpret_cast<const T*>(p.k) + (long)b * p.ks[0] + (long)n * p.ks[2];
+  const T* Vb = reinterpret_cast<const T*>(p.v) + (long)b * p.vs[0] + (long)n * p.vs[2];
+  const T* Ob = reinterpret_cast<const T*>(p.out) + (long)b * p.os[0] + (long)n * p.os[2];
+  const T* DOb = reinterpret_cast<const T*>(p.dout) + (long)b * p.os[0] + (long)n * p.os[2];
+  const auto rq = make_rsrc(Qb, (unsigned)(p.S - 1) * qs1b + 128);
+  const auto rk = make_rsrc(Kb, (unsigned)(p.S - 1) * ks1b + 128);
+  const auto rv = make_rsrc(Vb, (unsigned)(p.S - 1) * vs1b + 128);
+  const auto ro = make_rsrc(Ob, (unsigned)(p.S - 1) * os1b + 128);
+  const auto rdo = make_rsrc(DOb, (unsigned)(p.S - 1) * os1b + 128);
+  const unsigned voff_kc = (unsigned)(lane >> 3) * ks1b + (lane & 7) * 16;    // tile (coalesced) shape
+  const unsigned voff_vf = (unsigned)r * vs1b + 64 * h;                        // fragment shape
+
+  TileWalkLean w;
+  if (split_item) w.set_chunk(chunk * p.chunk_tiles, min(n_tiles, (chunk + 1) * p.chunk_tiles));
+  else w.set_band(p.pat, q0, p.S);
+  const int n_it = w.count();
+
+  Frag<T> qf, dof, vf;
+  bf16x8 kt[4];
+  float delta;
+  {
+    Frag<T> of;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      qf.v[s] = buf16(rq, (unsigned)r * qs1b + 64 * h + 16 * s, (unsigned)q0 * qs1b);
+      dof.v[s] = buf16(rdo, (unsigned)r * os1b + 64 * h + 16 * s, (unsigned)q0 * os1b);
+      of.v[s] = buf16(ro, (unsigned)r * os1b + 64 * h + 16 * s, (unsigned)q0 * os1b);
+    }
+    const unsigned k0 = (unsigned)w.at(0) * 32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) kt[u] = buf16(rk, voff_kc, (k0 + 8 * u) * ks1b);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) vf.v[s] = buf16(rv, voff_vf + 16 * s, k0 * vs1b);
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf((float)of.v[s][j], (float)dof.v[s][j], acc);
+    delta = acc + half_xchg(acc);
+  }
+  const long row_id = ((long)b * p.N + n) * p.S + min(q, p.S - 1);
+  if (!split_item && q_ok && h == 0) p.delta[row_id] = delta;
+  const float lse2 = p.lse[row_id] * kLog2e;
+
+  float relfn = 0.f, relfp = 0.f;
+  for (int i = lane; i < 32 * kTStride(Rp); i += 64) dtab[i] = 0.f;
+  if (HAS_REL) {
+    float* bias_ts = reinterpret_cast<float*>(xlds);
+    if (lane < Rp)
+      bias_ts[lane] = (p.bias && lane < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)lane * p.N + n] * p.tscale : 0.f;
+    const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
+    const unsigned es1b = (unsigned)p.N * 128;
+    const auto re = make_rsrc(Eb, (unsigned)(p.R - 1) * es1b + 128);
+    wave_lds_sync();
+#pragma unroll
+    for (int rb = 0; rb < Rp / 32; ++rb) {
+      Frag<T> ef;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ef.v[s] = buf16(re, (unsigned)r * es1b + 64 * h + 16 * s, (unsigned)(rb * 32) * es1b);
+      f32x16 c = {0};
+      c = mma_rows(ef, qf, c);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int id = rb * 32 + kap(i, h);
+        tab[r * kTStride(Rp) + tcol(1, m, id)] = fmaf(c[i], p.tscale, bias_ts[id]);
+      }
+    }
+    wave_lds_sync();
+    relfn = tab[r * kTStride(Rp)];
+    relfp = tab[r * kTStride(Rp) + 2 * m];
+  }
+  wave_lds_sync();
+
+  f32x16 a0 = {0}, a1 = {0};
+  float far_neg_acc = 0.f, far_pos_acc = 0.f;
+  const float* trow = tab + r * kTStride(Rp);
+  float* dtrow = dtab + r * kTStride(Rp);
+  const int trow_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)(tab + r * kTStride(Rp));
+  const uint32_t drop_base = drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q);
+
+  for (int it = 0; it < n_it; ++it) {
+    const int k0 = w.at(it) * 32;
+    tile_to_lds(xlds, kt, lane);
+    wave_lds_sync();
+    Frag<T> kf;
+    frag_from_tile(kf, xlds, lane);
+    f32x16 c = {0}, dp = {0};
+    c = mma_rows(kf, qf, c);      // S^T  [key x q]
+    dp = mma_rows(vf, dof, dp);   // dP^T [key x q]
+    if (it + 1 < n_it) {
+      const unsigned k1 = (unsigned)w.at(it + 1) * 32;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kt[u] = buf16(rk, voff_kc, (k1 + 8 * u) * ks1b);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) vf.v[s] = buf16(rv, voff_vf + 16 * s, k1 * vs1b);
+    }
+    const bool no_gkey = p.pat.ng == 0 || k0 + 31 < p.pat.g0 || k0 >= p.pat.g0 + p.pat.ng;
+    const TileClass tc = classify_tile(q0, k0, p.S, valid_len, W, m, ignore_band, no_gkey);
+    const bool one_id = !HAS_REL || tc.far_neg || tc.far_pos;
+    const float relc = HAS_REL ? (tc.far_neg ? relfn : relfp) : 0.f;
+    const int dbase = k0 - q + 4 * h;
+
+    float pr[16];
+    if (tc.plain && one_id) {                                   // class A
+      const float rc = relc - lse2;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rc));
+    } else if (tc.plain) {                                      // class B
+      const int abase = trow_addr + 4 * (m + dbase), alo = trow_addr, ahi = trow_addr + 8 * m;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int a = med3i(abase + 4 * ((i & 3) + 8 * (i >> 2)), alo, ahi);
+        pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)a) - lse2);
+      }
+    } else if (tc.edge && one_id) {                             // class D
+      const unsigned W2 = 2u * (unsigned)W;
+      const float rc = relc - lse2;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const unsigned dd = (unsigned)(dbase + (i & 3) + 8 * (i >> 2) + W);
+        pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rc) + (dd <= W2 ? 0.f : p.mask_add));
+      }
+    } else {                                                    // class C
+      const int kb = k0 + 4 * h;
+      const bool qv = q < valid_len;
+      const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2);
+        const int kk = kb + ci, d = dbase + ci;
+        const bool near = ignore_band | ((unsigned)(d + W) <= W2);
+        const bool gk = (unsigned)(kk - p.pat.g0) < (unsigned)p.pat.ng;
+        const bool seg = (kk < valid_len) == qv;
+        const bool keep = (int)seg & ((int)near | (int)gk);
+        float rel = 0.f;
+        if (HAS_REL) rel = trow[min(max(d, -m), m) + m];
+        float s = fmaf(c[i], p.sscale, rel);
+        s = keep ? s : s + p.mask_add;
+        pr[i] = (kk < p.S && q_ok) ? __builtin_amdgcn_exp2f(s - lse2) : 0.f;
+      }
+    }
+    // dS = P o (dP' - delta)
+    float ds[16];
+    if (p.drop_thresh) {
+#pragma unroll
+      for (int i = 0; i < 16; i += 2) {
+        const uint32_t hsh = drop_pair_hash(drop_base, (uint32_t)(k0 + kap(i, h)));
+        const float f0 = (hsh & 0xFFFFu) >= p.drop_thresh ? p.inv_keep : 0.f;
+        const float f1 = (hsh >> 16) >= p.drop_thresh ? p.inv_keep : 0.f;
+        ds[i] = pr[i] * (dp[i] * f0 - delta);
+        ds[i + 1] = pr[i + 1] * (dp[i + 1] * f1 - delta);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ds[i] = pr[i] * (dp[i] - delta);
+    }
+    // dRel (unscaled; rel_gscale applied at the flush / in the stores)
+    if (HAS_REL) {
+      if (one_id) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += ds[i];
+        if (tc.far_neg) far_neg_acc += t; else far_pos_acc += t;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int d = dbase + (i & 3) + 8 * (i >> 2);
+          const bool neg = d <= -m, pos = (d >= m) && !neg;
+          far_neg_acc += neg ? ds[i] : 0.f;
+          far_pos_acc += pos ? ds[i] : 0.f;
+          if (!neg && !pos) dtrow[m + d] = ds[i] * p.rel_gscale;
+        }
+      }
+    }
+    mma_xt(a0, a1, VTile<T>{}, xlds, ds, lane);   // dQ^T += K^T . dS^T   (gscale in the epilogue)
+    wave_lds_sync();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { a0[i] *= p.gscale; a1[i] *= p.gscale; }
+  if (HAS_REL) {
+    const float fn = (far_neg_acc + half_xchg(far_neg_acc)) * p.rel_gscale;
+    const float fp = (far_pos_acc + half_xchg(far_pos_acc)) * p.rel_gscale;
+    if (h == 0) {
+      if (m == 0) dtrow[0] = fn + fp;
+      else { dtrow[0] = fn; dtrow[2 * m] = fp; }
+    }
+  }
+  wave_lds_sync();
+
+  if (split_item) {
+    const long slot = ((long)bn * p.n_gblk + gblk) * p.n_chunks + chunk;
+    float* po = p.part_dq + slot * (32 * 64) + r * 64;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      *reinterpret_cast<f32x4*>(po + 8 * gi + 4 * h) = f32x4{a0[4 * gi], a0[4 * gi + 1], a0[4 * gi + 2], a0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(po + 32 + 8 * gi + 4 * h) = f32x4{a1[4 * gi], a1[4 * gi + 1], a1[4 * gi + 2], a1[4 * gi + 3]};
+    }
+    float* pt = p.part_dtab + slot * (32 * Rp);
+    for (int i = lane; i < 32 * Rp; i += 64) {
+      const int rr = i / Rp, id = i - rr * Rp;
+      pt[i] = dtab[rr * kTStride(Rp) + tcol(1, m, id)];
+    }
+    return;
+  }
+
+  if (HAS_REL) {
+    // (1) this wave's share of dE^T[d x id] and dbias[id] (lane = id)
+    {
+      bf16x8 qt[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) qt[u] = buf16(rq, (unsigned)(lane >> 3) * qs1b + (lane & 7) * 16, (unsigned)(q0 + 8 * u) * qs1b);
+      tile_to_lds(xlds, qt, lane);
+      wave_lds_sync();
+      const int widx = band_wg * 4 + wave;
+      float* pe = p.part_red + (long)widx * (Rp * 64 + Rp);
+#pragma unroll
+      for (int rb = 0; rb < Rp / 32; ++rb) {
+        const int id = rb * 32 + r;
+        const int col = tcol(1, m, id);
+        float vals[16], bsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int qq = q0 + kap(i, h);
+          const bool use = id < p.R && qq < p.S && !(p.skip_global && is_global(p.pat, qq));
+          vals[i] = use ? dtab[kap(i, h) * kTStride(Rp) + col] : 0.f;
+          bsum += vals[i];
+        }
+        bsum += half_xchg(bsum);
+        f32x16 e0 = {0}, e1 = {0};
+        mma_xt_hilo(e0, e1, VTile<T>{}, xlds, vals, lane);
+        float* row = pe + (long)id * 64;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+          *reinterpret_cast<f32x4*>(row + 8 * gi + 4 * h) = f32x4{e0[4 * gi], e0[4 * gi + 1], e0[4 * gi + 2], e0[4 * gi + 3]};
+          *reinterpret_cast<f32x4*>(row + 32 + 8 * gi + 4 * h) = f32x4{e1[4 * gi], e1[4 * gi + 1], e1[4 * gi + 2], e1[4 * gi + 3]};
+        }
+        if (h == 0) pe[Rp * 64 + id] = bsum;
+      }
+      wave_lds_sync();
+    }
+    // (2) dQ^T += E^T[d x id] . dRel^T[id x q]
+    const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
+    const unsigned es1b = (unsigned)p.N * 128;
+    const auto re = make_rsrc(Eb, (unsigned)(p.R - 1) * es1b + 128);
+#pragma unroll
+    for (int rb = 0; rb < Rp / 32; ++rb) {
+      float vals[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int id = rb * 32 + kap(i, h);
+        vals[i] = id < p.R ? dtrow[tcol(1, m, id)] : 0.f;
+      }
+      bf16x8 et[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) et[u] = buf16(re, (unsigned)(lane >> 3) * es1b + (lane & 7) * 16, (unsigned)(rb * 32 + 8 * u) * es1b);
+      tile_to_lds(xlds, et, lane);
+      wave_lds_sync();
+      mma_xt_hilo(a0, a1, VTile<T>{}, xlds, vals, lane);
+      wave_lds_sync();
+    }
+  }
+  if (!q_ok || (p.skip_global && is_global(p.pat, q))) return;
+  T* DQ = reinterpret_cast<T*>(p.dq) + (long)b * p.qs[0] + (long)q * p.qs[1] + (long)n * p.qs[2];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const int d = 8 * gi + 4 * h;
+    bf16x4 x, y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[j] = (__bf16)a0[4 * gi + j]; y[j] = (__bf16)a1[4 * gi + j]; }
+    *reinterpret_cast<bf16x4*>(DQ + d) = x;
+    *reinterpret_cast<bf16x4*>(DQ + 32 + d) = y;
+  }
+}
+
+// =========================================================================================
+// dK, dV (lane = key, registers = query rows).
+// =========================================================================================
+template <int Rp, bool HAS_REL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const BwdParams p) {
+  using T = __bf16;
+  using L = LeanLds<Rp>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  unsigned char* wl = smem + wave * L::kDkv;
+  float* tab = reinterpret_cast<float*>(wl);
+  unsigned char* qlds = wl + L::kTab;
+  unsigned char* dolds = qlds + L::kTile;
+  float* bias_ts = reinterpret_cast<float*>(dolds + L::kTile);
+  float* rowc = bias_ts + Rp;            // [0,32): lse * log2e, [32,64): delta of the current q tile
+
+  const int n_tiles = (p.S + 31) >> 5, nkb = (p.S + 127) >> 7;
+  const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
+  const int n_split_blocks = per_bn * p.B * p.N;
+  const bool split_item = (int)blockIdx.x < n_split_blocks;
+  int bn, k0, chunk = 0, gblk = 0;
+  if (split_item) {
+    bn = blockIdx.x / per_bn;
+    const int item = (blockIdx.x - bn * per_bn) * 4 + wave;
+    if (item >= p.n_chunks * p.n_gblk) return;
+    gblk = item / p.n_chunks;
+    chunk = item - gblk * p.n_chunks;
+    k0 = p.pat.g0 + gblk * 32;
+  } else {
+    const int wg = xcd_remap(blockIdx.x - n_split_blocks, p.n_band_blocks);
+    bn = wg / nkb;
+    k0 = (wg - bn * nkb) * 128 + wave * 32;
+    if (k0 >= p.S) return;
+  }
+  const int b = bn / p.N, n = bn - b * p.N;
+  const int k = k0 + r;
+  const bool k_ok = k < p.S;
+  const int valid_len = p.valid_len ? p.valid_len[b] : p.S;
+  const int W = p.pat.radius, m = p.pat.m;
+  const bool ignore_band = split_item;
+
+  const unsigned qs1b = (unsigned)p.qs[1] * 2, ks1b = (unsigned)p.ks[1] * 2, vs1b = (unsigned)p.vs[1] * 2, os1b = (unsigned)p.os[1] * 2;
+  const T* Qb = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)n * p.qs[2];
+  const T* Kb = reinterpret_cast<const T*>(p.k) + (long)b * p.ks[0] + (long)n * p.ks[2];
+  const T* Vb = reinterpret_cast<const T*>(p.v) + (long)b * p.vs[0] + (long)n * p.vs[2];
+  const T* DOb = reinterpret_cast<const T*>(p.dout) + (long)b * p.os[0] + (long)n * p.os[2];
+  const auto rq = make_rsrc(Qb, (unsigned)(p.S - 1) * qs1b + 128);
+  const auto rk = make_rsrc(Kb, (unsigned)(p.S - 1) * ks1b + 128);
+  const auto rv = make_rsrc(Vb, (unsigned)(p.S - 1) * vs1b + 128);
+  const auto rdo = make_rsrc(DOb, (unsigned)(p.S - 1) * os1b + 128);
+  const float* lse_bn = p.lse + ((long)b * p.N + n) * p.S;
+  const float* delta_bn = p.delta + ((long)b * p.N + n) * p.S;
+  const unsigned voff_qc = (unsigned)(lane >> 3) * qs1b + (lane & 7) * 16;
+  const unsigned voff_oc = (unsigned)(lane >> 3) * os1b + (lane & 7) * 16;
+
+  TileWalkLean w;
+  if (split_item) w.set_chunk(chunk * p.chunk_tiles, min(n_tiles, (chunk + 1) * p.chunk_tiles));
+  else w.set_band(p.pat, k0, p.S);
+  const int n_it = w.count();
+
+  Frag<T> kf, vf;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    kf.v[s] = buf16(rk, (unsigned)r * ks1b + 64 * h + 16 * s, (unsigned)k0 * ks1b);
+    vf.v[s] = buf16(rv, (unsigned)r * vs1b + 64 * h + 16 * s, (unsigned)k0 * vs1b);
+  }
+  bf16x8 qt[4], dot[4];
+  {
+    const unsigned q0 = (unsigned)w.at(0) * 32;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      qt[u] = buf16(rq, voff_qc, (q0 + 8 * u) * qs1b);
+      dot[u] = buf16(rdo, voff_oc, (q0 + 8 * u) * os1b);
+    }
+  }
+  const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
+  const unsigned es1b = (unsigned)p.N * 128;
+  const auto re = make_rsrc(HAS_REL ? (const void*)Eb : (const void*)Qb, HAS_REL ? (unsigned)(p.R - 1) * es1b + 128 : 0u);
+  Frag<T> ef[Rp / 32];                 // E rows stay in registers for the per-tile table rebuild
+  if (HAS_REL) {
+    if (lane < Rp)
+      bias_ts[lane] = (p.bias && lane < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)lane * p.N + n] * p.tscale : 0.f;
+#pragma unroll
+    for (int rb = 0; rb < Rp / 32; ++rb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ef[rb].v[s] = buf16(re, (unsigned)r * es1b + 64 * h + 16 * s, (unsigned)(rb * 32) * es1b);
+  }
+  wave_lds_sync();
+
+  f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
+  const int tab_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)tab;
+  const uint32_t bn_seed = mix32(p.seed_lo ^ ((uint32_t)bn * 0x9E3779B9u)) + p.seed_hi;
+
+  for (int it = 0; it < n_it; ++it) {
+    const int q0 = w.at(it) * 32;
+    tile_to_lds(qlds, qt, lane);
+    tile_to_lds(dolds, dot, lane);
+    if (it + 1 < n_it) {
+      const unsigned q1 = (unsigned)w.at(it + 1) * 32;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        qt[u] = buf16(rq, voff_qc, (q1 + 8 * u) * qs1b);
+        dot[u] = buf16(rdo, voff_oc, (q1 + 8 * u) * os1b);
+      }
+    }
+    // per-row constants of this q tile (one row per lane) -> LDS
+    {
+      const int qq = min(q0 + r, p.S - 1);
+      rowc[lane] = h == 0 ? lse_bn[qq] * kLog2e : delta_bn[qq];
+    }
+    wave_lds_sync();
+    Frag<T> qf;
+    frag_from_tile(qf, qlds, lane);
+    if (HAS_REL) {                      // T rows = this q tile, with -lse2[row] folded in
+      const float nl = -rowc[r];
+#pragma unroll
+      for (int rb = 0; rb < Rp / 32; ++rb) {
+        f32x16 c = {0};
+        c = mma_rows(ef[rb], qf, c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int id = rb * 32 + kap(i, h);
+          tab[r * kTStride(Rp) + tcol(1, m, id)] = fmaf(c[i], p.tscale, bias_ts[id]) + nl;
+        }
+      }
+      wave_lds_sync();
+    }
+    f32x16 c = {0}, dp = {0};
+    c = mma_rows(qf, kf, c);      // S  [q x key]
+    {
+      Frag<T> dof;
+      frag_from_tile(dof, dolds, lane);
+      dp = mma_rows(dof, vf, dp); // dP [q x key]
+    }
+    const bool no_gq = p.pat.ng == 0 || q0 + 31 < p.pat.g0 || q0 >= p.pat.g0 + p.pat.ng;
+    const TileClass tc = classify_tile(q0, k0, p.S, valid_len, W, m, ignore_band, no_gq);
+    const bool one_id = !HAS_REL || tc.far_neg || tc.far_pos;
+    const int dbase = k - q0 - 4 * h;                  // d_i = dbase - ci
+    const int col_c = tc.far_neg ? 0 : 2 * m;
+
+    float pr[16];
+    if (tc.plain && one_id) {                             // class A
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;   // q row inside the tile
+        const float rl = HAS_REL ? tab[row * kTStride(Rp) + col_c] : -rowc[row];   // rel - lse2
+        pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rl));
+      }
+    } else if (tc.plain) {                                // class B
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2), row = ci + 4 * h;
+        const int lo = tab_addr + row * kTStride(Rp) * 4;
+        const int a = med3i(lo + 4 * (m + dbase - ci), lo, lo + 8 * m);
+        pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)a));
+      }
+    } else if (tc.edge && one_id) {                       // class D
+      const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2), row = ci + 4 * h;
+        const float rl = HAS_REL ? tab[row * kTStride(Rp) + col_c] : -rowc[row];
+        const unsigned dd = (unsigned)(dbase - ci + W);
+        pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rl) + (dd <= W2 ? 0.f : p.mask_add));
+      }
+    } else {                                              // class C
+      const bool kv = k < valid_len;
+      const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2), row = ci + 4 * h;
+        const int qq = q0 + row, d = dbase - ci;
+        const bool near = ignore_band | ((unsigned)(d + W) <= W2);
+        const bool gq = (unsigned)(qq - p.pat.g0) < (unsigned)p.pat.ng;
+        const bool seg = kv == (qq < valid_len);
+        const bool keep = (int)seg & ((int)near | (int)gq);
+        const float rl = HAS_REL ? tab[row * kTStride(Rp) + min(max(d, -m), m) + m] : -rowc[row];
+        float s = fmaf(c[i], p.sscale, rl);
+        s = keep ? s : s + p.mask_add;
+        pr[i] = (qq < p.S && k_ok) ? __builtin_amdgcn_exp2f(s) : 0.f;
+      }
+    }
+    float g[16];
+    if (p.drop_thresh) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = q0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const uint32_t bits = drop_bits16(bn_seed + (uint32_t)qq * 0x85EBCA6Bu, (uint32_t)k);
+        const float df = bits >= p.drop_thresh ? p.inv_keep : 0.f;
+        g[i] = pr[i] * (dp[i] * df - rowc[32 + (i & 3) + 8 * (i >> 2) + 4 * h]);
+        pr[i] *= df;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) g[i] = pr[i] * (dp[i] - rowc[32 + (i & 3) + 8 * (i >> 2) + 4 * h]);
+    }
+    mma_xt(dv0, dv1, VTile<T>{}, dolds, pr, lane);   // dV^T[d x key] += dO^T[d x q] . P[q x key]
+    mma_xt(dk0, dk1, VTile<T>{}, qlds, g, lane);     // dK^T[d x key] += Q^T[d x q] . dS[q x key]
+    wave_lds_sync();
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk0[i] *= p.gscale; dk1[i] *= p.gscale; }
+
+  if (split_item) {
+    const long slot = ((long)bn * p.n_gblk + gblk) * p.n_chunks + chunk;
+    float* pk = p.part_dkv + slot * (2 * 32 * 64) + r * 64;
+    float* pv2 = pk + 32 * 64;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      *reinterpret_cast<f32x4*>(pk + 8 * gi + 4 * h) = f32x4{dk0[4 * gi], dk0[4 * gi + 1], dk0[4 * gi + 2], dk0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(pk + 32 + 8 * gi + 4 * h) = f32x4{dk1[4 * gi], dk1[4 * gi + 1], dk1[4 * gi + 2], dk1[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(pv2 + 8 * gi + 4 * h) = f32x4{dv0[4 * gi], dv0[4 * gi + 1], dv0[4 * gi + 2], dv0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(pv2 + 32 + 8 * gi + 4 * h) = f32x4{dv1[4 * gi], dv1[4 * gi + 1], dv1[4 * gi + 2], dv1[4 * gi + 3]};
+    }
+    return;
+  }
+  if (!k_ok || (p.skip_global && is_global(p.pat, k))) return;
+  T* DK = reinterpret_cast<T*>(p.dk) + (long)b * p.ks[0] + (long)k * p.ks[1] + (long)n * p.ks[2];
+  T* DV = reinterpret_cast<T*>(p.dv) + (long)b * p.vs[0] + (long)k * p.vs[1] + (long)n * p.vs[2];
+#pragma unroll
+  for (int gi = 0; gi < 4; ++gi) {
+    const int d = 8 * gi + 4 * h;
+    bf16x4 x, y, z, u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[j] = (__bf16)dk0[4 * gi + j]; y[j] = (__bf16)dk1[4 * gi + j];
+      z[j] = (__bf16)dv0[4 * gi + j]; u[j] = (__bf16)dv1[4 * gi + j];
+    }
+    *reinterpret_cast<bf16x4*>(DK + d) = x; *reinterpret_cast<bf16x4*>(DK + 32 + d) = y;
+    *reinterpret_cast<bf16x4*>(DV + d) = z; *reinterpret_cast<bf16x4*>(DV + 32 + d) = u;
+  }
+}
+
+// ------------------------------------ launcher --------------------------------------------
+template <int Rp, bool HAS_REL>
+static hipError_t launch_lean(const BwdParams& p, hipStream_t st) {
+  const int per_bn = (p.n_chunks * p.n_gblk + 3) / 4;
+  dim3 grid(p.n_band_blocks + per_bn * p.B * p.N);
+  const int lds_a = 4 * LeanLds<Rp>::kDq, lds_b = 4 * LeanLds<Rp>::kDkv;
+  if (lds_b > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_band_bf16_kernel<Rp, HAS_REL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+  hipLaunchKernelGGL((attn_bwd_dq_band_bf16_kernel<Rp, HAS_REL>), grid, dim3(256), lds_a, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (p.n_gblk > 0 && (e = launch_bwd_dq_combine(p, true, st)) != hipSuccess) return e;
+  hipLaunchKernelGGL((attn_bwd_dkv_band_bf16_kernel<Rp, HAS_REL>), grid, dim3(256), lds_b, st, p);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if (p.n_gblk > 0 && (e = launch_bwd_dkv_combine(p, true, st)) != hipSuccess) return e;
+  if (p.R > 0) e = launch_drel_reduce(p, true, st);
+  return e;
+}
+
+hipError_t launch_attn_bwd_band_bf16(const BwdParams& p, hipStream_t st) {
+  const bool has_rel = p.pat.id_mode == 1 && p.R > 0;
+  if (p.Rp == 32) return has_rel ? launch_lean<32, true>(p, st) : launch_lean<32, false>(p, st);
+  return has_rel ? launch_lean<64, true>(p, st) : launch_lean<64, false>(p, st);
+}
+
+}  // namespace mmt

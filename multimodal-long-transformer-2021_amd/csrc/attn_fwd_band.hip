@@ -12,24 +12,9 @@
 //     rides in the scalar offset, rows past the end read as zeros (no clamps, no 64-bit VALU);
 //   * compile-time HAS_REL; relative bias row staged through LDS once per q-block;
 //   * dropout: 16 random bits per element, one 32-bit mix per key pair.
-#include "attn_tile.h"
+#include "attn_lean.h"
 
 namespace mmt {
-
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-typedef __attribute__((address_space(3))) const float* lds_cfp;
-
-__device__ __forceinline__ bf16x8 buf16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ int med3i(int x, int lo, int hi) {
-  int r;
-  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
-  return r;
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
-}
 
 template <int Rp, bool HAS_REL>
 __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdParams p) {

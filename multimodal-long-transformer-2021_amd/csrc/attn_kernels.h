@@ -64,6 +64,10 @@ struct BwdParams {
 };
 
 hipError_t launch_attn_bwd(const BwdParams& p, int mode, bool bf16, hipStream_t st);
+hipError_t launch_attn_bwd_band_bf16(const BwdParams& p, hipStream_t st);   // attn_bwd_band.hip
+hipError_t launch_bwd_dq_combine(const BwdParams& p, bool bf16, hipStream_t st);
+hipError_t launch_bwd_dkv_combine(const BwdParams& p, bool bf16, hipStream_t st);
+hipError_t launch_drel_reduce(const BwdParams& p, bool bf16, hipStream_t st);
 
 struct SideParams {
   PatternDev pat;
