@@ -4,7 +4,7 @@ Host-side mirror (Python, like the reference) of the relative-attention path of
 `MmtEncoder`, over a C ABI (include/mmt_attn.h) into hand-written HIP kernels for gfx950.
 """
 from . import _lib
-from .ops import (AttentionPattern, relative_attention, relative_attention_backward,
+from .ops import (AttentionPattern, relative_attention, relative_attention_backward, relative_attention_qkv,
                   relative_attention_forward, side_inputs)
 
 from .encoder import MmtEncoder

@@ -104,17 +104,28 @@ class GradientBucketReducer:
       self.buckets.append(flat)
       self._pending.append(len(group))
     self._group_sizes = list(self._pending)
+    self.armed = True
     if self.world > 1:
       for p in self.params:
         p.register_post_accumulate_grad_hook(self._on_grad_ready)
+        # parameters whose gradient arrives through layers._CastParamFn bypass AccumulateGrad
+        p._mmt_grad_ready_hooks = (self._on_grad_ready,)
 
   def zero_grad(self):
     for b in self.buckets:
       b.zero_()
     self._pending = list(self._group_sizes)
     self._handles = []
+    self.armed = True
+
+  def set_armed(self, armed: bool):
+    """With gradient accumulation over micro-batches only the LAST backward may launch the
+    bucket all-reduces; earlier ones just accumulate locally."""
+    self.armed = bool(armed)
 
   def _on_grad_ready(self, p):
+    if not self.armed:
+      return
     gi = self._bucket_of[p]
     self._pending[gi] -= 1
     if self._pending[gi] == 0:

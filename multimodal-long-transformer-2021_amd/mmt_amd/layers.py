@@ -39,9 +39,39 @@ def get_activation(name_or_fn) -> Optional[Callable]:
   return table[name_or_fn]
 
 
+class _CastParamFn(torch.autograd.Function):
+  """fp32 master parameter -> compute dtype.  The backward accumulates the low-precision
+  gradient straight into `param.grad` (one mixed-precision add instead of a cast kernel plus an
+  add kernel) and then runs the parameter's gradient-ready hooks (the DP bucket reducer)."""
+
+  @staticmethod
+  def forward(ctx, param, dtype):
+    ctx.param = param
+    return param.detach().to(dtype)
+
+  @staticmethod
+  def backward(ctx, g):
+    param = ctx.param
+    if param.grad is None:
+      param.grad = g.to(param.dtype)
+    else:
+      param.grad.add_(g)
+    for hook in getattr(param, '_mmt_grad_ready_hooks', ()):
+      hook(param)
+    return None, None
+
+
+def cast_param(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+  if param.dtype == dtype:
+    return param
+  if not (torch.is_grad_enabled() and param.requires_grad):
+    return param.to(dtype)
+  return _CastParamFn.apply(param, dtype)
+
+
 def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
   """x @ W^T + b in x's dtype (fp32 master weights, bf16 compute)."""
-  return F.linear(x, weight.to(x.dtype), None if bias is None else bias.to(x.dtype))
+  return F.linear(x, cast_param(weight, x.dtype), None if bias is None else cast_param(bias, x.dtype))
 
 
 class EmbeddingLookup(nn.Module):
@@ -107,15 +137,14 @@ class RelativeAttention(nn.Module):
               training=False, dropout_seed=0, add_output_bias=True):
     B, S, H = x.shape
     qkv = _linear(x, self.qkv_weight, self.qkv_bias).view(B, S, 3, self.num_heads, self.head_size)
-    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-    emb = None if self.relative_emb_table is None else self.relative_emb_table.to(x.dtype)
-    bias = None if self.relative_bias_table is None else self.relative_bias_table.to(x.dtype)
+    emb = None if self.relative_emb_table is None else cast_param(self.relative_emb_table, x.dtype)
+    bias = None if self.relative_bias_table is None else cast_param(self.relative_bias_table, x.dtype)
     if relative_att_ids is None and (pattern is None or pattern.id_mode == 0):
       emb = bias = None
     self._calls += 1
     p_drop = self.att_dropout_prob if training else 0.0
-    out = ops.relative_attention(
-        q, k, v, emb, bias, att_mask=att_mask, relative_att_ids=relative_att_ids, pattern=pattern,
+    out = ops.relative_attention_qkv(
+        qkv, emb, bias, att_mask=att_mask, relative_att_ids=relative_att_ids, pattern=pattern,
         valid_len=valid_len, dropout_p=p_drop,
         dropout_seed=(int(dropout_seed) * 1000003 + self._calls) if p_drop > 0 else 0)
     return _linear(out.reshape(B, S, H), self.output_weight, self.output_bias if add_output_bias else None)
@@ -261,7 +290,9 @@ class MaskedLM(nn.Module):
       x = self.activation(x)
     x = F.layer_norm(x, self.layer_norm.normalized_shape, self.layer_norm.weight.to(x.dtype),
                      self.layer_norm.bias.to(x.dtype), self.layer_norm.eps)
-    logits = _linear(x, self.embedding_table, self.output_bias)
+    # the tied table also receives the embedding-lookup gradient through plain autograd, so it
+    # must not use the accumulate-in-backward cast (one gradient-ready event per parameter)
+    logits = F.linear(x, self.embedding_table.to(x.dtype), cast_param(self.output_bias, x.dtype))
     return logits.view(masked_positions.shape[0], masked_positions.shape[1], -1)
 
 

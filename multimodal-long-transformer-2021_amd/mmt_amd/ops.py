@@ -162,16 +162,21 @@ def side_inputs(pattern: AttentionPattern, num_image_wordpieces: torch.Tensor,
 def relative_attention_backward(dout, q, k, v, rel_emb, rel_bias, out, lse, *, att_mask=None,
                                 relative_att_ids=None, pattern: Optional[AttentionPattern] = None,
                                 valid_len=None, scale=None, mask_value=-10000.0,
-                                scale_before_add=False, dropout_p=0.0, dropout_seed=0):
+                                scale_before_add=False, dropout_p=0.0, dropout_seed=0, grads_out=None):
   """Backward of `relative_attention_forward` (recomputes P from `lse`).
 
-  Returns (dq, dk, dv, drel_emb, drel_bias); the table gradients are fp32."""
+  Returns (dq, dk, dv, drel_emb, drel_bias); the table gradients are fp32.  `grads_out` may
+  give preallocated (dq, dk, dv) with the strides of (q, k, v) -- e.g. the three slices of one
+  fused [B,S,3,N,D] gradient buffer."""
   R = _check_inputs(q, k, v, rel_emb, rel_bias, att_mask, relative_att_ids, valid_len)
   B, S, N, D = q.shape
   dout = dout if dout.stride() == out.stride() else dout.contiguous()
   if out.stride() != dout.stride():
     out = out.contiguous()
-  dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+  if grads_out is not None:
+    dq, dk, dv = grads_out
+  else:
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
   if dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != v.stride():
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
@@ -216,3 +221,36 @@ def relative_attention(q, k, v, rel_emb=None, rel_bias=None, **kw):
   mask_value, scale_before_add, dropout_p, dropout_seed)."""
   kw.pop('return_lse', None)
   return _RelativeAttentionFn.apply(q, k, v, rel_emb, rel_bias, kw)
+
+
+class _RelativeAttentionQkvFn(torch.autograd.Function):
+  """Same operator on the fused projection output qkv [B,S,3,N,D]: the backward writes dq, dk, dv
+  into the three slices of ONE gradient buffer (no per-slice zero-fill / copy in autograd)."""
+
+  @staticmethod
+  def forward(ctx, qkv, rel_emb, rel_bias, kw):
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    out, lse = relative_attention_forward(q, k, v, rel_emb, rel_bias, **kw)
+    ctx.save_for_backward(qkv, rel_emb, rel_bias, out, lse)
+    ctx.kw = kw
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    qkv, rel_emb, rel_bias, out, lse = ctx.saved_tensors
+    kw = {a: b for a, b in ctx.kw.items() if a != 'return_lse'}
+    dqkv = torch.empty_like(qkv)
+    _, _, _, de, db = relative_attention_backward(
+        dout, qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], rel_emb, rel_bias, out, lse,
+        grads_out=(dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]), **kw)
+    de = None if de is None else de.to(rel_emb.dtype)
+    db = None if db is None else db.to(rel_bias.dtype)
+    return dqkv, de, db, None
+
+
+def relative_attention_qkv(qkv, rel_emb=None, rel_bias=None, **kw):
+  """`relative_attention` on a fused, contiguous qkv [B,S,3,N,D] tensor."""
+  if qkv.dim() != 5 or qkv.shape[2] != 3 or not qkv.is_contiguous():
+    raise ValueError('qkv must be a contiguous [B,S,3,N,D] tensor')
+  kw.pop('return_lse', None)
+  return _RelativeAttentionQkvFn.apply(qkv, rel_emb, rel_bias, kw)

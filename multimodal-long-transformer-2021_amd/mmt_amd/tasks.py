@@ -82,6 +82,8 @@ class _TaskBase:
     is_t = lambda v: torch.is_tensor(v)
     for i in range(num_small_steps):
       # the reference takes the leading `micro` examples, then rotates them to the end
+      if reducer is not None:
+        reducer.set_armed(i == num_small_steps - 1)
       sl = slice(i * micro, (i + 1) * micro)
       small_inputs = {k: (v[sl] if is_t(v) else v) for k, v in inputs.items()}
       small_labels = {k: v[sl] for k, v in labels.items()}

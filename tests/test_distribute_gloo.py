@@ -31,7 +31,10 @@ def _worker(rank, world, port, reduce, out):
   x = torch.randn(4, 16, generator=g)
   for _ in range(2):                                    # two steps: zero_grad / re-arm
     reducer.zero_grad()
-    model(x).pow(2).mean().backward()
+    reducer.set_armed(False)                            # micro-step 1 of 2: accumulate locally only
+    (model(x[:2]).pow(2).sum() / 4).backward()
+    reducer.set_armed(True)                             # last micro-step launches the all-reduces
+    (model(x[2:]).pow(2).sum() / 4).backward()
     reducer.finish()
   out[rank] = [p.grad.clone() for p in params]
   dist.destroy_process_group()
