@@ -68,6 +68,11 @@ int mmt_bias_gelu_fwd(const mmt_rows_desc* desc, const void* u, const float* bia
 int mmt_bias_gelu_bwd(const mmt_rows_desc* desc, const void* dy, const void* u, const float* bias,
                       void* du, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 
+/* acc[i] += g[i] for i < n: fp32 master-gradient accumulation of a low-precision gradient
+ * (the `AccumulateGrad` step behind `optimizer.apply_gradients`, src/tasks/pretraining.py:262-273).
+ * g_dtype: MMT_F32 | MMT_BF16; acc must be 16-byte aligned, g 8-byte aligned. */
+int mmt_accumulate_grad(float* acc, const void* g, int32_t g_dtype, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -319,6 +319,24 @@ __global__ __launch_bounds__(256) void bias_gelu_kernel(const LayerParams p) {
   }
 }
 
+// acc[i] += g[i]: 8 elements per thread, grid-stride.
+template <typename T>
+__global__ __launch_bounds__(256) void accumulate_grad_kernel(float* acc, const T* g, long n) {
+  const long nch = n >> 3;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < nch; c += (long)gridDim.x * 256) {
+    float a[8], b[8];
+    Chunk<float>::load(acc + c * 8, a);
+    Chunk<T>::load(g + c * 8, b);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] += b[i];
+    Chunk<float>::store(acc + c * 8, a);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long i = (nch << 3) + threadIdx.x;
+    acc[i] += (float)g[i];
+  }
+}
+
 }  // namespace mmt
 
 // =============================================================================================
@@ -451,6 +469,19 @@ int mmt_residual_block_bwd(const mmt_rows_desc* d, const void* dx_new_in, const 
   hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((ksets * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, ksets, d->H, dbias, dgamma, dbeta);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_residual_block_bwd reduce: %s", hipGetErrorString(e));
+}
+
+int mmt_accumulate_grad(float* acc, const void* g, int32_t g_dtype, int64_t n, void* stream) {
+  if (!acc || !g || n <= 0) return lfail(MMT_E_INVALID, "mmt_accumulate_grad: NULL argument or n <= 0");
+  if (g_dtype != MMT_F32 && g_dtype != MMT_BF16) return lfail(MMT_E_INVALID, "mmt_accumulate_grad: bad dtype");
+  if (((uintptr_t)acc & 15) || ((uintptr_t)g & (g_dtype == MMT_BF16 ? 15 : 15)))
+    return lfail(MMT_E_INVALID, "mmt_accumulate_grad: buffers must be 16-byte aligned");
+  long blocks = ((n >> 3) + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  if (g_dtype == MMT_BF16) hipLaunchKernelGGL(mmt::accumulate_grad_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, acc, (const __bf16*)g, (long)n);
+  else hipLaunchKernelGGL(mmt::accumulate_grad_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, acc, (const float*)g, (long)n);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_accumulate_grad: %s", hipGetErrorString(e));
 }
 
 int mmt_bias_gelu_fwd(const mmt_rows_desc* d, const void* u, const float* bias, void* y, void* stream) {

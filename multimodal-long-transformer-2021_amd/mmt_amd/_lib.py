@@ -22,7 +22,7 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
            'mmt_attn_bwd', 'mmt_side_inputs',
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
-           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd')
+           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_accumulate_grad')
 
 
 class RowsDesc(ctypes.Structure):
@@ -107,6 +107,8 @@ def lib() -> ctypes.CDLL:
   L.mmt_ln_bwd.argtypes = [rd] + [vp] * 9 + [ctypes.c_size_t, vp]
   L.mmt_residual_block_bwd.argtypes = [rd] + [vp] * 12 + [ctypes.c_size_t, vp]
   L.mmt_bias_gelu_bwd.argtypes = [rd] + [vp] * 6 + [ctypes.c_size_t, vp]
+  L.mmt_accumulate_grad.restype = ctypes.c_int
+  L.mmt_accumulate_grad.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
   if L.mmt_abi_version() != MMT_ABI_VERSION:
     raise ImportError('libmmt_attn ABI version mismatch')
   _lib = L

@@ -94,12 +94,13 @@ class GradientBucketReducer:
       cur.append(p); cur_bytes += nbytes
     if cur:
       groups.append(cur)
+    pad4 = lambda n: (n + 3) & ~3      # keep every gradient view 16-byte aligned
     for gi, group in enumerate(groups):
-      flat = torch.zeros(sum(p.numel() for p in group), dtype=torch.float32, device=group[0].device)
+      flat = torch.zeros(sum(pad4(p.numel()) for p in group), dtype=torch.float32, device=group[0].device)
       off = 0
       for p in group:
         p.grad = flat[off:off + p.numel()].view_as(p)
-        off += p.numel()
+        off += pad4(p.numel())
         self._bucket_of[p] = gi
       self.buckets.append(flat)
       self._pending.append(len(group))

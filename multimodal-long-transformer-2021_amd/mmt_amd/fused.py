@@ -178,3 +178,15 @@ class _BiasGeluFn(torch.autograd.Function):
 def bias_gelu(u, bias):
   """gelu_tanh(u + bias)."""
   return _BiasGeluFn.apply(u, bias)
+
+
+def accumulate_grad_(acc: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+  """acc (fp32, contiguous) += g (fp32 | bf16), one streaming kernel."""
+  if (not acc.is_cuda or acc.dtype != torch.float32 or not acc.is_contiguous() or not g.is_contiguous()
+      or g.dtype not in (torch.float32, torch.bfloat16) or acc.numel() != g.numel()
+      or acc.data_ptr() % 16 or g.data_ptr() % 16):
+    return acc.add_(g)
+  code = _lib.MMT_F32 if g.dtype == torch.float32 else _lib.MMT_BF16
+  with torch.cuda.device(acc.device):
+    _lib.check(_lib.lib().mmt_accumulate_grad(acc.data_ptr(), g.data_ptr(), code, acc.numel(), _stream(acc)))
+  return acc

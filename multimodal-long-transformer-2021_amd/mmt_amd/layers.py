@@ -55,7 +55,7 @@ class _CastParamFn(torch.autograd.Function):
     if param.grad is None:
       param.grad = g.to(param.dtype)
     else:
-      param.grad.add_(g)
+      fused.accumulate_grad_(param.grad, g)
     for hook in getattr(param, '_mmt_grad_ready_hooks', ()):
       hook(param)
     return None, None

@@ -114,3 +114,15 @@ def test_errors():
     fused.layer_norm(x, torch.ones(12, device='cuda'), torch.zeros(12, device='cuda'))
   with pytest.raises(RuntimeError, match='GPU only'):
     fused.layer_norm(torch.zeros(4, 16), torch.ones(16), torch.zeros(16))
+
+
+@pytest.mark.parametrize('n', [8, 1000, 768 * 3072 + 5])
+@pytest.mark.parametrize('gdt', [torch.float32, torch.bfloat16])
+def test_accumulate_grad(n, gdt):
+  from mmt_amd import fused
+  torch.manual_seed(n)
+  acc = torch.randn(n, device='cuda')
+  g = torch.randn(n, device='cuda').to(gdt)
+  want = acc + g.float()
+  fused.accumulate_grad_(acc, g)
+  assert torch.equal(acc, want)        # one fp32 add per element: bit-exact
