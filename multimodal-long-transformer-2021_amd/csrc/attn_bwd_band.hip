@@ -15,7 +15,7 @@ template <int Rp> struct LeanLds {
   static constexpr int kTab = (32 * kTStride(Rp) * 4 + 15) & ~15;
   static constexpr int kTile = 32 * 128;
   static constexpr int kDq = 2 * kTab + kTile;            // T, dT, K/Q/E tile (bias row aliases the tile)
-  static constexpr int kDkv = kTab + 2 * kTile + Rp * 4 + 256;  // T, Q tile, dO tile, bias row, lse2/delta rows
+  static constexpr int kDkv = kTab + 2 * kTile + Rp * 4 + 512;  // T, Q tile, dO tile, bias row, per-row constants
 };
 
 __device__ __forceinline__ void tile_to_lds(unsigned char* lds, const bf16x8 (&v)[4], int lane) {
@@ -143,6 +143,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     wave_lds_sync();
     relfn = tab[r * kTStride(Rp)];
     relfp = tab[r * kTStride(Rp) + 2 * m];
+    if (!split_item && q_ok && h == 0) {   // reused by the dK/dV pass for its one-id tiles
+      p.relfar[row_id * 2] = relfn;
+      p.relfar[row_id * 2 + 1] = relfp;
+    }
   }
   wave_lds_sync();
 
@@ -363,7 +367,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   unsigned char* qlds = wl + L::kTab;
   unsigned char* dolds = qlds + L::kTile;
   float* bias_ts = reinterpret_cast<float*>(dolds + L::kTile);
-  float* rowc = bias_ts + Rp;            // [0,32): lse * log2e, [32,64): delta of the current q tile
+  float* rowc = bias_ts + Rp;            // per row of the current q tile: [0,32) lse*log2e, [32,64) delta,
+                                         // [64,96) rel(clipped, d<=-m) - lse2, [96,128) rel(clipped, d>=m) - lse2
 
   const int n_tiles = (p.S + 31) >> 5, nkb = (p.S + 127) >> 7;
   const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
@@ -401,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   const auto rdo = make_rsrc(DOb, (unsigned)(p.S - 1) * os1b + 128);
   const float* lse_bn = p.lse + ((long)b * p.N + n) * p.S;
   const float* delta_bn = p.delta + ((long)b * p.N + n) * p.S;
+  const float* relfar_bn = p.relfar + ((long)b * p.N + n) * p.S * 2;
   const unsigned voff_qc = (unsigned)(lane >> 3) * qs1b + (lane & 7) * 16;
   const unsigned voff_oc = (unsigned)(lane >> 3) * os1b + (lane & 7) * 16;
 
@@ -427,14 +433,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
   const unsigned es1b = (unsigned)p.N * 128;
   const auto re = make_rsrc(HAS_REL ? (const void*)Eb : (const void*)Qb, HAS_REL ? (unsigned)(p.R - 1) * es1b + 128 : 0u);
-  Frag<T> ef[Rp / 32];                 // E rows stay in registers for the per-tile table rebuild
   if (HAS_REL) {
     if (lane < Rp)
       bias_ts[lane] = (p.bias && lane < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)lane * p.N + n] * p.tscale : 0.f;
-#pragma unroll
-    for (int rb = 0; rb < Rp / 32; ++rb)
-#pragma unroll
-      for (int s = 0; s < 4; ++s) ef[rb].v[s] = buf16(re, (unsigned)r * es1b + 64 * h + 16 * s, (unsigned)(rb * 32) * es1b);
   }
   wave_lds_sync();
 
@@ -457,17 +458,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
     // per-row constants of this q tile (one row per lane) -> LDS
     {
       const int qq = min(q0 + r, p.S - 1);
-      rowc[lane] = h == 0 ? lse_bn[qq] * kLog2e : delta_bn[qq];
+      const float l2 = lse_bn[qq] * kLog2e;
+      rowc[lane] = h == 0 ? l2 : delta_bn[qq];
+      if (HAS_REL) rowc[64 + lane] = relfar_bn[2 * qq + h] - l2;
     }
+    const bool no_gq = p.pat.ng == 0 || q0 + 31 < p.pat.g0 || q0 >= p.pat.g0 + p.pat.ng;
+    const TileClass tc = classify_tile(q0, k0, p.S, valid_len, W, m, ignore_band, no_gq);
+    const bool one_id = !HAS_REL || tc.far_neg || tc.far_pos;
     wave_lds_sync();
     Frag<T> qf;
     frag_from_tile(qf, qlds, lane);
-    if (HAS_REL) {                      // T rows = this q tile, with -lse2[row] folded in
+    if (HAS_REL && !one_id) {           // mixed ids: T rows = this q tile, with -lse2[row] folded in
       const float nl = -rowc[r];
 #pragma unroll
       for (int rb = 0; rb < Rp / 32; ++rb) {
+        Frag<T> ef;                     // E rows: L2-resident, only the mixed-id tiles need them
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ef.v[s] = buf16(re, (unsigned)r * es1b + 64 * h + 16 * s, (unsigned)(rb * 32) * es1b);
         f32x16 c = {0};
-        c = mma_rows(ef[rb], qf, c);
+        c = mma_rows(ef, qf, c);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int id = rb * 32 + kap(i, h);
@@ -483,18 +492,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       frag_from_tile(dof, dolds, lane);
       dp = mma_rows(dof, vf, dp); // dP [q x key]
     }
-    const bool no_gq = p.pat.ng == 0 || q0 + 31 < p.pat.g0 || q0 >= p.pat.g0 + p.pat.ng;
-    const TileClass tc = classify_tile(q0, k0, p.S, valid_len, W, m, ignore_band, no_gq);
-    const bool one_id = !HAS_REL || tc.far_neg || tc.far_pos;
     const int dbase = k - q0 - 4 * h;                  // d_i = dbase - ci
-    const int col_c = tc.far_neg ? 0 : 2 * m;
+    const float* relrow = rowc + (tc.far_neg ? 64 : 96);   // clipped rel - lse2, per row
 
     float pr[16];
     if (tc.plain && one_id) {                             // class A
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * h;   // q row inside the tile
-        const float rl = HAS_REL ? tab[row * kTStride(Rp) + col_c] : -rowc[row];   // rel - lse2
+        const float rl = HAS_REL ? relrow[row] : -rowc[row];   // rel - lse2
         pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rl));
       }
     } else if (tc.plain) {                                // class B
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int ci = (i & 3) + 8 * (i >> 2), row = ci + 4 * h;
-        const float rl = HAS_REL ? tab[row * kTStride(Rp) + col_c] : -rowc[row];
+        const float rl = HAS_REL ? relrow[row] : -rowc[row];
         const unsigned dd = (unsigned)(dbase - ci + W);
         pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rl) + (dd <= W2 ? 0.f : p.mask_add));
       }
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
         const bool gq = (unsigned)(qq - p.pat.g0) < (unsigned)p.pat.ng;
         const bool seg = kv == (qq < valid_len);
         const bool keep = (int)seg & ((int)near | (int)gq);
-        const float rl = HAS_REL ? tab[row * kTStride(Rp) + min(max(d, -m), m) + m] : -rowc[row];
+        const float rl = !HAS_REL ? -rowc[row] : (one_id ? relrow[row] : tab[row * kTStride(Rp) + min(max(d, -m), m) + m]);
         float s = fmaf(c[i], p.sscale, rl);
         s = keep ? s : s + p.mask_add;
         pr[i] = (qq < p.S && k_ok) ? __builtin_amdgcn_exp2f(s) : 0.f;

@@ -55,6 +55,7 @@ struct BwdParams {
   float inv_keep;
   // workspace
   float* delta;      // [B,N,S]       rowsum(dO * O)
+  float* relfar;     // [B,N,S,2]     clipped-id relative scores of each row (log2 domain), lean path
   float* drel;       // [B*N, n_global, Rp]  d(relall) rows of the global tokens, id order
   float* part_dq;    // [B*N, n_gblk, n_chunks, 32, 64]   global-row partials
   float* part_dtab;  // [B*N, n_gblk, n_chunks, 32, Rp]

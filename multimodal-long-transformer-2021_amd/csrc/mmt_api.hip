@@ -38,7 +38,7 @@ struct Plan {
   size_t fwd_ws;     // bytes
   size_t bwd_ws;
   int n_split;
-  size_t off_delta, off_drel, off_pdq, off_pdtab, off_pdkv, off_red;  // float offsets
+  size_t off_delta, off_relfar, off_drel, off_pdq, off_pdtab, off_pdkv, off_red;  // float offsets
 };
 
 int check_desc(const mmt_attn_desc* d) {
@@ -94,7 +94,8 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
   const size_t bn = (size_t)d->B * d->N, Rp = d->R <= 32 ? 32 : 64;
   pl.n_split = (int)std::min<size_t>(256, ((size_t)d->B * d->S + 255) / 256);
   pl.off_delta = 0;
-  pl.off_drel = pl.off_delta + bn * d->S;
+  pl.off_relfar = pl.off_delta + bn * d->S;
+  pl.off_drel = pl.off_relfar + bn * d->S * 2;
   pl.off_pdq = pl.off_drel + bn * (size_t)d->mask.n_global * Rp;
   pl.off_pdtab = pl.off_pdq + bn * pl.n_rowblk * pl.n_chunks * (32 * 64);
   pl.off_pdkv = pl.off_pdtab + bn * pl.n_rowblk * pl.n_chunks * (32 * Rp);
@@ -213,7 +214,7 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   p.perm_1d = (!dense && p.pat.id_mode == MMT_IDS_1D && desc->R >= 2 * p.pat.m + 1) ? 1 : 0;
   p.drop_thresh = f.drop_thresh; p.seed_lo = f.seed_lo; p.seed_hi = f.seed_hi; p.inv_keep = f.inv_keep;
   float* ws = reinterpret_cast<float*>(workspace);
-  p.delta = ws + pl.off_delta; p.drel = ws + pl.off_drel; p.part_dq = ws + pl.off_pdq;
+  p.delta = ws + pl.off_delta; p.relfar = ws + pl.off_relfar; p.drel = ws + pl.off_drel; p.part_dq = ws + pl.off_pdq;
   p.part_dtab = ws + pl.off_pdtab; p.part_dkv = ws + pl.off_pdkv; p.part_red = ws + pl.off_red;
   p.n_band_blocks = desc->B * desc->N * ((desc->S + 127) / 128);
   p.n_split = pl.n_split;
