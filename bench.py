@@ -173,7 +173,8 @@ def main():
     pass
   roofline = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
               'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic,
-              'kernel': 'attn_fwd (band + global keys/rows), per launch of B=4',
+              'kernel': 'one attention-forward call, B=4: attn_fwd_band_bf16_kernel (band + global-key tiles + '
+                        'global-row chunks) followed by attn_rows_combine_kernel',
               'launch_us': round(attn_ms * 1e3, 2),
               'algorithmic_bytes_per_launch': byts * B,
               'mfma_tflops': round(tfs, 2), 'mfma_frac': round(tfs / MFMA_BF16_PEAK_TF, 5)}

@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
 
   const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
   const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
-  const int n_split_blocks = per_bn * p.B * p.N;          // long items first
+  // long (global-row) items first, then the band blocks with the XCD remap: measured 8 % faster
+  // for this kernel than the plane-major order the forward and dK/dV kernels use
+  const int n_split_blocks = per_bn * p.B * p.N;
   const bool split_item = (int)blockIdx.x < n_split_blocks;
   int bn, q0, chunk = 0, gblk = 0, band_wg = 0;
   if (split_item) {
@@ -372,20 +374,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
 
   const int n_tiles = (p.S + 31) >> 5, nkb = (p.S + 127) >> 7;
   const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
-  const int n_split_blocks = per_bn * p.B * p.N;
-  const bool split_item = (int)blockIdx.x < n_split_blocks;
-  int bn, k0, chunk = 0, gblk = 0;
+  int bn, k0, chunk = 0, gblk = 0, blk;
+  plane_major_map(blockIdx.x, p.B * p.N, per_bn, nkb, bn, blk);
+  const bool split_item = blk < per_bn;
   if (split_item) {
-    bn = blockIdx.x / per_bn;
-    const int item = (blockIdx.x - bn * per_bn) * 4 + wave;
+    const int item = blk * 4 + wave;
     if (item >= p.n_chunks * p.n_gblk) return;
     gblk = item / p.n_chunks;
     chunk = item - gblk * p.n_chunks;
     k0 = p.pat.g0 + gblk * 32;
   } else {
-    const int wg = xcd_remap(blockIdx.x - n_split_blocks, p.n_band_blocks);
-    bn = wg / nkb;
-    k0 = (wg - bn * nkb) * 128 + wave * 32;
+    k0 = (blk - per_bn) * 128 + wave * 32;
     if (k0 >= p.S) return;
   }
   const int b = bn / p.N, n = bn - b * p.N;

@@ -29,25 +29,23 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
 
   // ---- work item ------------------------------------------------------------------------
   const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
-  // the (longer) global-row items come first in the grid so that the tail of the launch is
-  // made of short band items
-  const int per_bn = (p.n_chunks * p.n_rowblk + 3) >> 2;
-  const int n_rows_blocks = per_bn * p.B * p.N;
-  const bool rows_item = (int)blockIdx.x < n_rows_blocks;
+  const int per_bn = (p.n_chunks * p.n_rowblk + 3) >> 2;     // global-row blocks per plane
   int bn, q0, chunk = 0, rowblk = 0;
-  if (rows_item) {
-    const int rb = blockIdx.x;
-    bn = rb / per_bn;
-    const int item = (rb - bn * per_bn) * 4 + wave;
-    if (item >= p.n_chunks * p.n_rowblk) return;
-    rowblk = item / p.n_chunks;
-    chunk = item - rowblk * p.n_chunks;
-    q0 = p.pat.g0 + rowblk * 32;
-  } else {
-    const int wg = xcd_remap(blockIdx.x - n_rows_blocks, p.n_band_blocks);
-    bn = wg / nqb;
-    q0 = (wg - bn * nqb) * 128 + wave * 32;
-    if (q0 >= p.S) return;
+  bool rows_item;
+  {
+    int blk;
+    plane_major_map(blockIdx.x, p.B * p.N, per_bn, nqb, bn, blk);
+    rows_item = blk < per_bn;
+    if (rows_item) {
+      const int item = blk * 4 + wave;
+      if (item >= p.n_chunks * p.n_rowblk) return;
+      rowblk = item / p.n_chunks;
+      chunk = item - rowblk * p.n_chunks;
+      q0 = p.pat.g0 + rowblk * 32;
+    } else {
+      q0 = (blk - per_bn) * 128 + wave * 32;
+      if (q0 >= p.S) return;
+    }
   }
   const int b = bn / p.N, n = bn - b * p.N;
   const int q = q0 + r;

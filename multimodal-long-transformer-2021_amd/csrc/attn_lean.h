@@ -41,6 +41,25 @@ struct TileWalkLean {
   }
 };
 
+// Block -> (plane bn, block-in-plane) map shared by the lean kernels.  Blocks are dealt round-robin
+// over the 8 XCDs, so block bid runs on XCD group bid % 8; each group walks its share of the (b,n)
+// planes one after the other and, per plane, first the `per_bn` split blocks (global rows / keys)
+// and then the `nblk` band blocks: every reader of one plane's Q/K/V shares one L2 and runs back
+// to back.  Speed only -- any placement is correct.  blk < per_bn <=> split block.
+__device__ __forceinline__ void plane_major_map(int bid, int BN, int per_bn, int nblk, int& bn, int& blk) {
+  if ((BN & 7) == 0) {
+    const int per_plane = per_bn + nblk, planes_per_xcd = BN >> 3;
+    const int x = bid & 7, i = bid >> 3;
+    const int pl = i / per_plane;
+    bn = x * planes_per_xcd + pl;
+    blk = i - pl * per_plane;
+  } else {                              // fallback: all split blocks first, then the band blocks
+    const int n_split = per_bn * BN;
+    if (bid < n_split) { bn = bid / per_bn; blk = bid - bn * per_bn; }
+    else { const int wg = bid - n_split; bn = wg / nblk; blk = per_bn + wg - bn * nblk; }
+  }
+}
+
 // Wave-uniform class of one 32x32 tile of (row-block x0, other-block y0), d = key - query.
 //   dmin / dmax : extreme key-query distances inside the tile
 struct TileClass {

@@ -150,3 +150,31 @@ def test_config3_shape_against_oracle_sample():
   ones = torch.ones_like(dev(v))
   out1, _ = mmt_amd.relative_attention_forward(dev(q), dev(k), ones, dev(emb), dev(bias), pattern=pat)
   assert float((out1.float() - 1).abs().max()) < 1e-2     # rows of P sum to 1
+
+
+@pytest.mark.parametrize('ng', [8, 128])
+def test_config5_shape_forward_backward(ng):
+  """BASELINE config 5 shape (S=8192 = 2+88^2+446, radius 64, g globals, bf16): one head against the
+  dense oracle (forward), all heads finite + normalised; backward finite and dV rows sum to dO."""
+  import mmt_amd
+  B, S, N, R = 1, 8192, 2, 32
+  g0 = 2 + 88 * 88
+  q, k, v, emb, bias = attention_inputs(B, S, N, R, seed=11)
+  q, k, v, emb, bias = (bf16_round(x) for x in (q, k, v, emb, bias))
+  pat = mmt_amd.AttentionPattern(local_radius=64, global_start=g0, n_global=ng, id_mode=1, max_dist=12)
+  dev = lambda x: torch.from_numpy(x).cuda().to(torch.bfloat16)
+  tq, tk, tv = (dev(x).requires_grad_(True) for x in (q, k, v))
+  te, tb = dev(emb).requires_grad_(True), dev(bias).requires_grad_(True)
+  out = mmt_amd.relative_attention(tq, tk, tv, te, tb, pattern=pat)
+  got = out.detach().float().cpu().numpy()
+  assert np.isfinite(got).all()
+  mask, ids = dense_side_inputs(1, S, None, 64, g0, ng, 1, 12)
+  ref, _ = oa.relative_attention_fwd(q[:, :, :1], k[:, :, :1], v[:, :, :1], emb[:, :1], bias[:, :1], mask, ids)
+  assert np.abs(got[:, :, :1] - ref).max() < BF16_TOL
+  dout = torch.ones_like(out)
+  out.backward(dout)
+  for t in (tq, tk, tv, te, tb):
+    assert torch.isfinite(t.grad.float()).all()
+  # every row of P sums to 1, so sum_k dV[k] = sum_q dO[q] per head
+  dv_sum = tv.grad.float().sum(dim=1)
+  assert float((dv_sum - float(S)).abs().max()) < 0.02 * S
