@@ -31,6 +31,9 @@ typedef struct mmt_rows_desc {
   float eps;           /* LayerNorm epsilon (1e-12 in the reference)    */
   float dropout_p;     /* hidden_dropout_prob; 0 disables               */
   uint64_t dropout_seed;
+  int32_t accumulate;  /* backward: != 0 adds dbias / dgamma / dbeta INTO the given buffers (fp32
+                          master gradients) instead of overwriting them                       */
+  int32_t reserved;
 } mmt_rows_desc;
 
 /* Bytes of scratch the *_bwd entry points need (column-sum partials). */

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void resid_ln_bwd_kernel(const LayerParams p) 
 // out[j][col] = sum_blocks part[block][j][col]   (fixed order).  Workgroup = 64 columns x 16
 // block groups; every thread sums nblocks/16 partials (unrolled), LDS combines the groups.
 __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, int nblocks, int ksets, int H,
-                                                             float* o0, float* o1, float* o2) {
+                                                             float* o0, float* o1, float* o2, int accumulate) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
   const int idx = blockIdx.x * 64 + lane;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, 
     for (int g = 0; g < 16; ++g) s += red[g][lane];
     const int set = idx / H, col = idx - set * H;
     float* dst = set == 0 ? o0 : (set == 1 ? o1 : o2);
-    dst[col] = s;
+    dst[col] = accumulate ? dst[col] + s : s;
   }
 }
 
@@ -429,7 +429,7 @@ int mmt_ln_bwd(const mmt_rows_desc* d, const void* dy, const void* x, const floa
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = launch_bwd<false, true>(p, d->dtype == MMT_BF16, st, p.nblocks);
   if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_ln_bwd: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((2 * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, 2, d->H, dgamma, dbeta, (float*)nullptr);
+  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((2 * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, 2, d->H, dgamma, dbeta, (float*)nullptr, d->accumulate);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_ln_bwd reduce: %s", hipGetErrorString(e));
 }
@@ -466,7 +466,7 @@ int mmt_residual_block_bwd(const mmt_rows_desc* d, const void* dx_new_in, const 
   hipError_t e = has_ln ? launch_bwd<true, true>(p, bf16, st, p.nblocks) : launch_bwd<true, false>(p, bf16, st, p.nblocks);
   if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_residual_block_bwd: %s", hipGetErrorString(e));
   const int ksets = has_ln ? 3 : 1;
-  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((ksets * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, ksets, d->H, dbias, dgamma, dbeta);
+  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((ksets * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, ksets, d->H, dbias, dgamma, dbeta, d->accumulate);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_residual_block_bwd reduce: %s", hipGetErrorString(e));
 }
@@ -513,7 +513,7 @@ int mmt_bias_gelu_bwd(const mmt_rows_desc* d, const void* dy, const void* u, con
   else hipLaunchKernelGGL((mmt::bias_gelu_kernel<float, true>), grid, dim3(256), 0, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_bias_gelu_bwd: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((d->H + 63) / 64), dim3(1024), 0, st, p.part, (int)gy, 1, d->H, dbias, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((d->H + 63) / 64), dim3(1024), 0, st, p.part, (int)gy, 1, d->H, dbias, (float*)nullptr, (float*)nullptr, d->accumulate);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_bias_gelu_bwd reduce: %s", hipGetErrorString(e));
 }

@@ -28,7 +28,8 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
 class RowsDesc(ctypes.Structure):
   _fields_ = [('rows', ctypes.c_int64), ('H', ctypes.c_int32), ('dtype', ctypes.c_int32),
               ('eps', ctypes.c_float), ('dropout_p', ctypes.c_float),
-              ('dropout_seed', ctypes.c_uint64)]
+              ('dropout_seed', ctypes.c_uint64), ('accumulate', ctypes.c_int32),
+              ('reserved', ctypes.c_int32)]
 
 
 class MaskDesc(ctypes.Structure):

@@ -146,8 +146,8 @@ class GradientBucketReducer:
     self._handles = []
 
   def clip_by_global_norm(self, max_norm: float) -> torch.Tensor:
-    total = torch.sqrt(sum((b.float() ** 2).sum() for b in self.buckets))
+    norms = torch._foreach_norm(self.buckets)                 # one pass, no temporaries
+    total = torch.linalg.vector_norm(torch.stack(norms))
     scale = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-    for b in self.buckets:
-      b.mul_(scale)
+    torch._foreach_mul_(self.buckets, scale)
     return total

@@ -56,6 +56,24 @@ def _f32(t):
   return t if t.dtype == torch.float32 and t.is_contiguous() else t.float().contiguous()
 
 
+def _grad_target(param, like):
+  """Where a parameter gradient goes: straight into an existing fp32 `.grad` (accumulate, no
+  AccumulateGrad add kernel) when possible, else a fresh buffer handed back to autograd."""
+  g = getattr(param, 'grad', None)
+  direct = (isinstance(param, torch.nn.Parameter) and g is not None and g.dtype == torch.float32
+            and g.is_contiguous() and g.shape == like.shape and g.data_ptr() % 16 == 0)
+  return (g, True) if direct else (torch.empty_like(like), False)
+
+
+def _finish(param, buf, direct):
+  """Return value for autograd + gradient-ready notification for directly written grads."""
+  if not direct:
+    return buf
+  for hook in getattr(param, '_mmt_grad_ready_hooks', ()):
+    hook(param)
+  return None
+
+
 class _LayerNormFn(torch.autograd.Function):
 
   @staticmethod
@@ -63,6 +81,7 @@ class _LayerNormFn(torch.autograd.Function):
     _check(x, gamma, beta)
     shape = x.shape
     x2 = x.reshape(-1, shape[-1]).contiguous()
+    gamma_p, beta_p = gamma, beta
     gamma, beta = _f32(gamma), _f32(beta)
     y = torch.empty_like(x2)
     mean = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
@@ -72,20 +91,26 @@ class _LayerNormFn(torch.autograd.Function):
       _lib.check(_lib.lib().mmt_ln_fwd(d, _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _stream(x)))
     ctx.save_for_backward(x2, gamma, mean, rstd)
     ctx.eps, ctx.shape = eps, shape
+    ctx.params = (gamma_p, beta_p)
     return y.view(shape)
 
   @staticmethod
   def backward(ctx, dy):
     x2, gamma, mean, rstd = ctx.saved_tensors
+    gamma_p, beta_p = ctx.params
     dy2 = dy.reshape(x2.shape).contiguous()
     dx = torch.empty_like(x2)
-    dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+    (dg, dg_direct), (db, db_direct) = _grad_target(gamma_p, gamma), _grad_target(beta_p, gamma)
+    direct = dg_direct and db_direct
+    if not direct:
+      dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
     d = _desc(x2, ctx.eps)
+    d.accumulate = int(direct)
     ws = _ws(d, x2)
     with torch.cuda.device(x2.device):
       _lib.check(_lib.lib().mmt_ln_bwd(d, _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg),
                                        _p(db), _p(ws), ws.numel(), _stream(x2)))
-    return dx.view(ctx.shape), dg, db, None
+    return dx.view(ctx.shape), _finish(gamma_p, dg, direct), _finish(beta_p, db, direct), None
 
 
 def layer_norm(x, gamma, beta, eps=1e-12):
@@ -101,6 +126,7 @@ class _ResidualBlockFn(torch.autograd.Function):
     _check(o, bias, x, gamma, beta)
     shape = x.shape
     o2, x2 = o.reshape(-1, shape[-1]).contiguous(), x.reshape(-1, shape[-1]).contiguous()
+    ctx.params = (bias, gamma, beta)
     bias = _f32(bias)
     has_ln = gamma is not None
     if has_ln:
@@ -128,16 +154,26 @@ class _ResidualBlockFn(torch.autograd.Function):
     if has_ln and dh2 is None:
       dh2 = torch.zeros_like(x_new)
     d_o, dx = torch.empty_like(x_new), torch.empty_like(x_new)
-    dbias = torch.empty_like(bias)
-    dg = torch.empty_like(gamma) if has_ln else None
-    db = torch.empty_like(gamma) if has_ln else None
+    bias_p, gamma_p, beta_p = ctx.params
+    dbias, direct = _grad_target(bias_p, bias)
+    dg = db = None
+    if has_ln:
+      (dg, d1), (db, d2) = _grad_target(gamma_p, gamma), _grad_target(beta_p, gamma)
+      direct = direct and d1 and d2
+    if not direct:
+      dbias = torch.empty_like(bias)
+      dg = torch.empty_like(gamma) if has_ln else None
+      db = torch.empty_like(gamma) if has_ln else None
     d = _desc(x_new, eps, p, seed)
+    d.accumulate = int(direct)
     ws = _ws(d, x_new)
     with torch.cuda.device(x_new.device):
       _lib.check(_lib.lib().mmt_residual_block_bwd(
           d, _p(dxn), _p(dh2), _p(x_new), _p(gamma), _p(mean), _p(rstd), _p(d_o), _p(dx), _p(dbias),
           _p(dg), _p(db), _p(ws), ws.numel(), _stream(x_new)))
-    return d_o.view(shape), dbias, dx.view(shape), dg, db, None, None, None
+    return (d_o.view(shape), _finish(bias_p, dbias, direct), dx.view(shape),
+            _finish(gamma_p, dg, direct) if has_ln else None,
+            _finish(beta_p, db, direct) if has_ln else None, None, None, None)
 
 
 def residual_block(o, bias, x, gamma=None, beta=None, eps=1e-12, p=0.0, seed=0):
@@ -152,6 +188,7 @@ class _BiasGeluFn(torch.autograd.Function):
     _check(u, bias)
     shape = u.shape
     u2 = u.reshape(-1, shape[-1]).contiguous()
+    ctx.param = bias
     bias = _f32(bias)
     y = torch.empty_like(u2)
     d = _desc(u2)
@@ -166,13 +203,14 @@ class _BiasGeluFn(torch.autograd.Function):
     u2, bias = ctx.saved_tensors
     dy2 = dy.reshape(u2.shape).contiguous()
     du = torch.empty_like(u2)
-    dbias = torch.empty_like(bias)
+    dbias, direct = _grad_target(ctx.param, bias)
     d = _desc(u2)
+    d.accumulate = int(direct)
     ws = _ws(d, u2)
     with torch.cuda.device(u2.device):
       _lib.check(_lib.lib().mmt_bias_gelu_bwd(d, _p(dy2), _p(u2), _p(bias), _p(du), _p(dbias), _p(ws),
                                               ws.numel(), _stream(u2)))
-    return du.view(ctx.shape), dbias
+    return du.view(ctx.shape), _finish(ctx.param, dbias, direct)
 
 
 def bias_gelu(u, bias):
