@@ -76,6 +76,27 @@ int mmt_bias_gelu_bwd(const mmt_rows_desc* desc, const void* dy, const void* u, 
  * g_dtype: MMT_F32 | MMT_BF16; acc must be 16-byte aligned, g 8-byte aligned. */
 int mmt_accumulate_grad(float* acc, const void* g, int32_t g_dtype, int64_t n, void* stream);
 
+/* One AdamW step over a flat parameter slab (the optimizer of the reference's trainer config,
+ * src/configs/pretraining_experiments.py:24-47: adamw, weight_decay_rate 0.01 with the
+ * LayerNorm/bias exclusion list, applied after the gradient all-reduce of
+ * src/tasks/pretraining.py:273).  Per element i of chunk c = i / 1024:
+ *   g = grad[i] * (*grad_scale)                      (global-norm clip factor, device scalar, may be NULL)
+ *   p = param[i] * (1 - lr * chunk_wd[c]);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+ *   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)            (torch.optim.AdamW semantics)
+ * writes param, exp_avg, exp_avg_sq (fp32), the bf16 shadow copy (nullable) and, with
+ * zero_grad != 0, clears grad.  n must be a multiple of 1024; all buffers 16-byte aligned. */
+typedef struct mmt_adamw_desc {
+  int64_t n;
+  float lr, beta1, beta2, eps;
+  float bias_correction1, bias_correction2;   /* 1 - beta^t */
+  int32_t zero_grad;
+  int32_t reserved;
+} mmt_adamw_desc;
+
+int mmt_adamw_step(const mmt_adamw_desc* desc, float* param, float* grad, float* exp_avg,
+                   float* exp_avg_sq, void* param_bf16, const float* chunk_wd,
+                   const float* grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 
@@ -337,6 +338,39 @@ __global__ __launch_bounds__(256) void accumulate_grad_kernel(float* acc, const 
   }
 }
 
+// AdamW over a flat slab; one block = one 1024-element chunk (4 elements per thread).
+struct AdamwParams {
+  float lr, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2;
+  int zero_grad;
+};
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ prm, float* __restrict__ grd,
+                                                    float* __restrict__ m1, float* __restrict__ m2,
+                                                    __bf16* __restrict__ shadow, const float* __restrict__ chunk_wd,
+                                                    const float* __restrict__ grad_scale, long n_chunks, AdamwParams a) {
+  const float gs = grad_scale ? *grad_scale : 1.f;
+  for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const long i = c * 1024 + threadIdx.x * 4;
+    const float decay = 1.f - a.lr * chunk_wd[c];
+    const f32x4 p4 = *reinterpret_cast<const f32x4*>(prm + i), g4 = *reinterpret_cast<const f32x4*>(grd + i);
+    f32x4 a4 = *reinterpret_cast<const f32x4*>(m1 + i), b4 = *reinterpret_cast<const f32x4*>(m2 + i), o4;
+    bf16x4 s4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g = g4[j] * gs;
+      const float mm = a.beta1 * a4[j] + (1.f - a.beta1) * g;
+      const float vv = a.beta2 * b4[j] + (1.f - a.beta2) * g * g;
+      const float denom = sqrtf(vv) * a.inv_sqrt_bc2 + a.eps;
+      const float pn = p4[j] * decay - a.lr * a.inv_bc1 * (mm / denom);
+      a4[j] = mm; b4[j] = vv; o4[j] = pn; s4[j] = (__bf16)pn;
+    }
+    *reinterpret_cast<f32x4*>(prm + i) = o4;
+    *reinterpret_cast<f32x4*>(m1 + i) = a4;
+    *reinterpret_cast<f32x4*>(m2 + i) = b4;
+    if (shadow) *reinterpret_cast<bf16x4*>(shadow + i) = s4;
+    if (a.zero_grad) *reinterpret_cast<f32x4*>(grd + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
 }  // namespace mmt
 
 // =============================================================================================
@@ -482,6 +516,20 @@ int mmt_accumulate_grad(float* acc, const void* g, int32_t g_dtype, int64_t n, v
   else hipLaunchKernelGGL(mmt::accumulate_grad_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, acc, (const float*)g, (long)n);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_accumulate_grad: %s", hipGetErrorString(e));
+}
+
+int mmt_adamw_step(const mmt_adamw_desc* d, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                   void* param_bf16, const float* chunk_wd, const float* grad_scale, void* stream) {
+  if (!d || !param || !grad || !exp_avg || !exp_avg_sq || !chunk_wd) return lfail(MMT_E_INVALID, "mmt_adamw_step: NULL argument");
+  if (d->n <= 0 || (d->n & 1023)) return lfail(MMT_E_INVALID, "mmt_adamw_step: n must be a positive multiple of 1024");
+  if (!(d->bias_correction1 > 0.f) || !(d->bias_correction2 > 0.f)) return lfail(MMT_E_INVALID, "mmt_adamw_step: bias corrections must be positive");
+  mmt::AdamwParams a{d->lr, d->beta1, d->beta2, d->eps, 1.f / d->bias_correction1, 1.f / sqrtf(d->bias_correction2), d->zero_grad};
+  const long n_chunks = d->n >> 10;
+  const long blocks = n_chunks < 8192 ? n_chunks : 8192;
+  hipLaunchKernelGGL(mmt::adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, (__bf16*)param_bf16, chunk_wd, grad_scale, n_chunks, a);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_adamw_step: %s", hipGetErrorString(e));
 }
 
 int mmt_bias_gelu_fwd(const mmt_rows_desc* d, const void* u, const float* bias, void* y, void* stream) {

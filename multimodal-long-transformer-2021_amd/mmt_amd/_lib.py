@@ -22,7 +22,7 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
            'mmt_attn_bwd', 'mmt_side_inputs',
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
-           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_accumulate_grad')
+           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_accumulate_grad', 'mmt_adamw_step')
 
 
 class RowsDesc(ctypes.Structure):
@@ -47,6 +47,13 @@ class AttnDesc(ctypes.Structure):
               ('scale', ctypes.c_float), ('mask_value', ctypes.c_float),
               ('flags', ctypes.c_uint32), ('dropout_p', ctypes.c_float),
               ('dropout_seed', ctypes.c_uint64), ('mask', MaskDesc)]
+
+
+class AdamwDesc(ctypes.Structure):
+  _fields_ = [('n', ctypes.c_int64), ('lr', ctypes.c_float), ('beta1', ctypes.c_float),
+              ('beta2', ctypes.c_float), ('eps', ctypes.c_float), ('bias_correction1', ctypes.c_float),
+              ('bias_correction2', ctypes.c_float), ('zero_grad', ctypes.c_int32),
+              ('reserved', ctypes.c_int32)]
 
 
 class MmtError(RuntimeError):
@@ -108,6 +115,8 @@ def lib() -> ctypes.CDLL:
   L.mmt_ln_bwd.argtypes = [rd] + [vp] * 9 + [ctypes.c_size_t, vp]
   L.mmt_residual_block_bwd.argtypes = [rd] + [vp] * 12 + [ctypes.c_size_t, vp]
   L.mmt_bias_gelu_bwd.argtypes = [rd] + [vp] * 6 + [ctypes.c_size_t, vp]
+  L.mmt_adamw_step.restype = ctypes.c_int
+  L.mmt_adamw_step.argtypes = [ctypes.POINTER(AdamwDesc)] + [vp] * 8
   L.mmt_accumulate_grad.restype = ctypes.c_int
   L.mmt_accumulate_grad.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
   if L.mmt_abi_version() != MMT_ABI_VERSION:

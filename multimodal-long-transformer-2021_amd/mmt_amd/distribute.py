@@ -83,6 +83,8 @@ class GradientBucketReducer:
     self.world = strategy.num_replicas_in_sync
     self.params = [p for p in params if p.requires_grad]
     self.buckets: List[torch.Tensor] = []
+    self.layout = []            # (param, bucket index, element offset) for flat optimizers
+    self.buckets_are_zero = True
     self._bucket_of, self._pending, self._handles = {}, [], []
     order = list(reversed(self.params))
     cur, cur_bytes = [], 0
@@ -94,12 +96,13 @@ class GradientBucketReducer:
       cur.append(p); cur_bytes += nbytes
     if cur:
       groups.append(cur)
-    pad4 = lambda n: (n + 3) & ~3      # keep every gradient view 16-byte aligned
+    pad4 = lambda n: (n + 1023) & ~1023   # every parameter owns whole 1024-element chunks (fused AdamW)
     for gi, group in enumerate(groups):
       flat = torch.zeros(sum(pad4(p.numel()) for p in group), dtype=torch.float32, device=group[0].device)
       off = 0
       for p in group:
         p.grad = flat[off:off + p.numel()].view_as(p)
+        self.layout.append((p, gi, off))
         off += pad4(p.numel())
         self._bucket_of[p] = gi
       self.buckets.append(flat)
@@ -113,8 +116,10 @@ class GradientBucketReducer:
         p._mmt_grad_ready_hooks = (self._on_grad_ready,)
 
   def zero_grad(self):
-    for b in self.buckets:
-      b.zero_()
+    if not self.buckets_are_zero:      # a fused optimizer step may already have cleared them
+      for b in self.buckets:
+        b.zero_()
+    self.buckets_are_zero = False
     self._pending = list(self._group_sizes)
     self._handles = []
     self.armed = True
@@ -145,9 +150,12 @@ class GradientBucketReducer:
           b.mul_(1.0 / self.world)
     self._handles = []
 
-  def clip_by_global_norm(self, max_norm: float) -> torch.Tensor:
+  def clip_by_global_norm(self, max_norm: float, apply: bool = True) -> torch.Tensor:
+    """Returns the clip factor min(1, max_norm / ||g||) as a device scalar; with apply=False the
+    gradients are left alone (a fused optimizer multiplies them while it reads them)."""
     norms = torch._foreach_norm(self.buckets)                 # one pass, no temporaries
     total = torch.linalg.vector_norm(torch.stack(norms))
-    scale = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-    torch._foreach_mul_(self.buckets, scale)
-    return total
+    scale = torch.clamp(max_norm / (total + 1e-6), max=1.0).float()
+    if apply:
+      torch._foreach_mul_(self.buckets, scale)
+    return scale

@@ -47,6 +47,9 @@ class _CastParamFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, param, dtype):
     ctx.param = param
+    shadow = getattr(param, '_mmt_shadow', None)      # kept current by optimization.FusedAdamW
+    if shadow is not None and shadow.dtype == dtype:
+      return shadow
     return param.detach().to(dtype)
 
   @staticmethod

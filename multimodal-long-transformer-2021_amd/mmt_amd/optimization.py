@@ -28,7 +28,67 @@ def split_decay_groups(named_params, exclude_patterns):
   return decay, no_decay
 
 
-def create_optimizer(model: torch.nn.Module, cfg: OptimizerConfig) -> torch.optim.Optimizer:
+class FusedAdamW:
+  """AdamW over the reducer's flat layout: one `mmt_adamw_step` launch per gradient bucket updates
+  the fp32 master parameters and moments, applies the global-norm clip factor while reading the
+  gradients, writes the bf16 shadow weights the forward pass uses (`param._mmt_shadow`) and
+  clears the gradient bucket.  Same update rule as torch.optim.AdamW."""
+
+  def __init__(self, named_params, cfg: OptimizerConfig, reducer, shadow_dtype=torch.bfloat16):
+    from . import _lib
+    self._lib = _lib
+    self.cfg, self.reducer = cfg, reducer
+    self.param_groups = [{'lr': cfg.initial_learning_rate}]
+    self.t = 0
+    names = {p: n for n, p in named_params}
+    self.slabs = []
+    for gi, grad in enumerate(reducer.buckets):
+      n = grad.numel()
+      dev = grad.device
+      slab = dict(grad=grad, param=torch.zeros(n, device=dev), m=torch.zeros(n, device=dev),
+                  v=torch.zeros(n, device=dev), shadow=torch.zeros(n, device=dev, dtype=shadow_dtype),
+                  wd=torch.zeros(n >> 10, device=dev))
+      self.slabs.append(slab)
+    for p, gi, off in reducer.layout:
+      slab = self.slabs[gi]
+      k = p.numel()
+      slab['param'][off:off + k].copy_(p.data.reshape(-1))
+      p.data = slab['param'][off:off + k].view_as(p)              # re-home the parameter
+      excluded = any(re.search(pat, names.get(p, '')) for pat in cfg.exclude_from_weight_decay)
+      slab['wd'][off >> 10:(off + k + 1023) >> 10] = 0.0 if excluded else cfg.weight_decay_rate
+      p._mmt_shadow = slab['shadow'][off:off + k].view_as(p)
+    for slab in self.slabs:
+      slab['shadow'].copy_(slab['param'])
+
+  def zero_grad(self, set_to_none: bool = False):
+    self.reducer.zero_grad()
+
+  @torch.no_grad()
+  def step(self, grad_scale=None):
+    self.t += 1
+    c = self.cfg
+    d = self._lib.AdamwDesc()
+    d.lr, d.beta1, d.beta2, d.eps = self.param_groups[0]['lr'], c.beta_1, c.beta_2, c.epsilon
+    d.bias_correction1, d.bias_correction2 = 1 - c.beta_1 ** self.t, 1 - c.beta_2 ** self.t
+    d.zero_grad = 1
+    L = self._lib.lib()
+    for slab in self.slabs:
+      d.n = slab['grad'].numel()
+      dev = slab['grad'].device
+      with torch.cuda.device(dev):
+        self._lib.check(L.mmt_adamw_step(
+            d, slab['param'].data_ptr(), slab['grad'].data_ptr(), slab['m'].data_ptr(), slab['v'].data_ptr(),
+            slab['shadow'].data_ptr(), slab['wd'].data_ptr(),
+            None if grad_scale is None else grad_scale.data_ptr(),
+            torch.cuda.current_stream(dev).cuda_stream))
+    self.reducer.buckets_are_zero = True
+
+
+def create_optimizer(model: torch.nn.Module, cfg: OptimizerConfig, reducer=None):
+  """torch.optim.AdamW (fused) by default; with a gradient reducer on the GPU, the flat
+  `FusedAdamW` that shares the reducer's bucket layout."""
+  if reducer is not None and all(p.is_cuda for p in reducer.params):
+    return FusedAdamW(list(model.named_parameters()), cfg, reducer)
   decay, no_decay = split_decay_groups(model.named_parameters(), cfg.exclude_from_weight_decay)
   groups = [{'params': decay, 'weight_decay': cfg.weight_decay_rate},
             {'params': no_decay, 'weight_decay': 0.0}]

@@ -95,13 +95,18 @@ class _TaskBase:
         grad_loss = loss / num_small_steps
       grad_loss.backward()
       all_loss = all_loss + (loss / num_small_steps).detach()
+    fused_opt = hasattr(optimizer, 'slabs')          # optimization.FusedAdamW
+    scale = None
     if reducer is not None:
       reducer.finish()                   # gradient all-reduce == optimizer.apply_gradients(:273)
       if clip_norm:
-        reducer.clip_by_global_norm(clip_norm)
+        scale = reducer.clip_by_global_norm(clip_norm, apply=not fused_opt)
     elif clip_norm:
       torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
-    optimizer.step()
+    if fused_opt:
+      optimizer.step(grad_scale=scale)
+    else:
+      optimizer.step()
     return {self.loss: all_loss}
 
   @torch.no_grad()

@@ -32,9 +32,9 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
   torch.manual_seed(0)     # identical initial weights on every replica
   model = task.build_model().to(device)
   opt_cfg = params.trainer.optimizer_config
-  optimizer = optimization.create_optimizer(model, opt_cfg)
   reducer = strategy.make_reducer(list(model.parameters()),
                                   reduce='sum' if not params.task.scale_loss and os.environ.get('MMT_REFERENCE_SUM') else 'mean')
+  optimizer = optimization.create_optimizer(model, opt_cfg, reducer=reducer)
   data = task.build_inputs(params.task.train_data, device=device, rank=strategy.rank)
   steps = max_steps or params.trainer.train_steps
   logs = []

@@ -126,3 +126,35 @@ def test_accumulate_grad(n, gdt):
   want = acc + g.float()
   fused.accumulate_grad_(acc, g)
   assert torch.equal(acc, want)        # one fp32 add per element: bit-exact
+
+
+def test_fused_adamw_matches_torch_adamw():
+  """mmt_adamw_step (flat, clip factor folded in, bf16 shadow, grad cleared) vs torch.optim.AdamW."""
+  from mmt_amd import configs, distribute, optimization
+  def make():
+    torch.manual_seed(0)
+    m = torch.nn.Module()
+    m.dense_weight = torch.nn.Parameter(torch.randn(130, 70, device='cuda'))
+    m.dense_bias = torch.nn.Parameter(torch.randn(130, device='cuda'))
+    m.layer_norm = torch.nn.LayerNorm(70).cuda()
+    return m
+  cfg = configs.OptimizerConfig(initial_learning_rate=1e-2)
+  ref_m, our_m = make(), make()
+  ref_opt = optimization.create_optimizer(ref_m, cfg)
+  reducer = distribute.DataParallelStrategy(None).make_reducer(list(our_m.parameters()))
+  our_opt = optimization.create_optimizer(our_m, cfg, reducer=reducer)
+  assert isinstance(our_opt, optimization.FusedAdamW)
+  for step in range(3):
+    reducer.zero_grad()
+    for (_, pr), (_, po) in zip(ref_m.named_parameters(), our_m.named_parameters()):
+      g = torch.randn_like(pr) * (3.0 if step == 1 else 0.1)
+      pr.grad = g.clone()
+      po.grad.copy_(g)
+    torch.nn.utils.clip_grad_norm_(ref_m.parameters(), 1.0)
+    scale = reducer.clip_by_global_norm(1.0, apply=False)
+    ref_opt.step()
+    our_opt.step(grad_scale=scale)
+    for (n, pr), (_, po) in zip(ref_m.named_parameters(), our_m.named_parameters()):
+      assert float((pr - po).abs().max()) < 2e-6, (step, n)
+      assert torch.equal(po._mmt_shadow, po.detach().to(torch.bfloat16)), n
+      assert float(po.grad.abs().max()) == 0.0
