@@ -97,6 +97,19 @@ int mmt_adamw_step(const mmt_adamw_desc* desc, float* param, float* grad, float*
                    float* exp_avg_sq, void* param_bf16, const float* chunk_wd,
                    const float* grad_scale, void* stream);
 
+/* Weight gradient of a Dense layer, accumulated into the fp32 master gradient:
+ *   dw[M,N] += dy[K,M]^T . x[K,N]        (bf16 operands, fp32 accumulation, float atomics)
+ * = the per-layer `tape.gradient` product + `AccumulateGrad` of src/tasks/pretraining.py:262-296.
+ * Requires M % 128 == 0, N % 256 == 0, K % 32 == 0, 16-byte aligned operands, ld* in elements
+ * (ldy, ldx multiples of 8); returns MMT_E_UNSUPPORTED otherwise (callers fall back to a
+ * library GEMM).  With a workspace of mmt_wgrad_workspace_bytes() the split-K partials are
+ * written as plain fp32 slabs and summed in fixed order (bitwise reproducible); without one they
+ * are added with float atomics (order not fixed). */
+size_t mmt_wgrad_workspace_bytes(int32_t M, int32_t N, int64_t K);
+int mmt_wgrad_accumulate(float* dw, int64_t ldw, const void* dy, int64_t ldy, const void* x,
+                         int64_t ldx, int32_t M, int32_t N, int64_t K, void* workspace,
+                         size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,224 @@
+// Weight-gradient GEMM for gfx950:  dW[M,N] += dY[K,M]^T . X[K,N]   (bf16 in, fp32 accumulate)
+//
+// This is the `tape.gradient` product behind every Dense layer of the encoder
+// (src/tasks/pretraining.py:292-296): K = B*S rows (16384 at BASELINE config 3) are contracted,
+// M = output features, N = input features, both operands row-major with the contracted index as
+// the slow dimension -- the layout hipBLASLt handles worst (175-490 TF/s measured).
+//
+// Structure: workgroup tile 128 (M) x 256 (N), 4 waves of 64 x 128 (128 accumulator registers),
+// split-K over the rows.  Per 32-row step the dY and X slabs are staged row-major in LDS
+// (register-staged, double-buffered) in the 32 x 128-byte tile format of the attention kernels;
+// BOTH MFMA operands are then "column reads" of those tiles, fetched with ds_read_b64_tr_b16 in
+// the same k-permuted order (attn_tile.h: mma_xt), so no transposed copy of either matrix ever
+// exists.  The epilogue adds the fp32 tile into the master-gradient buffer with float atomics
+// (one 128-byte row segment per half-wave, adders = split-K factor), i.e. the gradient
+// accumulation (`AccumulateGrad`) is fused and dW is never rounded to bf16.
+#include "../../include/mmt_attn.h"
+#include "../../include/mmt_layer.h"
+#include "attn_tile.h"
+#include "mmt_err.h"
+
+namespace mmt {
+
+constexpr int kWgTM = 128, kWgTN = 256, kWgStageBytes = (kWgTM + kWgTN) * 32 * 2;   // 24 KiB
+
+struct WgradParams {
+  const __bf16* dy;   // [K, M] row stride ldy
+  const __bf16* x;    // [K, N] row stride ldx
+  float* dw;          // [M, N] row stride ldw (fp32, accumulated into)
+  float* slabs;       // [split, M, N] fp32 partials (plain stores) or NULL -> float atomics into dw
+  long ldy, ldx, ldw;
+  int M, N, K;
+  int tiles_n, k_per_split;   // rows per split-K slice (multiple of 32)
+};
+
+__device__ __forceinline__ int vtile_off(int row, int ch) {      // byte offset inside one 32x128B tile
+  return row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, li = lane & 15, cb = (lane >> 4) & 1, r = lane & 31;
+  const int tile = blockIdx.x, ks = blockIdx.y;
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
+  const int m0 = tm * kWgTM, n0 = tn * kWgTN;
+  const int k_begin = ks * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int n_steps = (k_end - k_begin) >> 5;
+  if (n_steps <= 0) return;
+
+  // ---- staging map: 16-byte chunks; A slab 32 x 128 cols = 512 chunks (2 per thread),
+  //      B slab 32 x 256 cols = 1024 chunks (4 per thread) -------------------------------------
+  const __bf16* ga[2]; int la[2];
+  const __bf16* gb[4]; int lb[4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int c = tid + 256 * u, row = c >> 4, ch = c & 15;
+    ga[u] = p.dy + (long)(k_begin + row) * p.ldy + m0 + ch * 8;
+    la[u] = (ch >> 3) * 4096 + vtile_off(row, ch & 7);
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int c = tid + 256 * u, row = c >> 5, ch = c & 31;
+    gb[u] = p.x + (long)(k_begin + row) * p.ldx + n0 + ch * 8;
+    lb[u] = kWgTM * 64 + (ch >> 3) * 4096 + vtile_off(row, ch & 7);
+  }
+  const long astep = 32 * p.ldy, bstep = 32 * p.ldx;
+
+  // ---- fragment read offsets (k-step s adds 16 rows = 2048 B; second read is 8 rows = 1024 B on)
+  const int frow = 4 * h + (li >> 2);
+  int fo[2];      // column block db = 0/1 inside a tile
+#pragma unroll
+  for (int db = 0; db < 2; ++db) fo[db] = frow * 128 + ((db ^ ((frow >> 1) & 1)) << 6) + 32 * cb + 8 * (li & 3);
+  const int a_tile = (wave & 1) * 4096;                              // this wave's 64 M columns
+  const int b_tile = kWgTM * 64 + (wave >> 1) * 2 * 4096;            // this wave's 128 N columns
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x16{0};
+
+  bf16x8 ra[2], rb[4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const bf16x8*>(ga[u]);
+#pragma unroll
+  for (int u = 0; u < 4; ++u) rb[u] = *reinterpret_cast<const bf16x8*>(gb[u]);
+#pragma unroll
+  for (int u = 0; u < 2; ++u) *reinterpret_cast<bf16x8*>(smem + la[u]) = ra[u];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) *reinterpret_cast<bf16x8*>(smem + lb[u]) = rb[u];
+  __syncthreads();
+
+  for (int step = 0; step < n_steps; ++step) {
+    unsigned char* cur = smem + (step & 1) * kWgStageBytes;
+    unsigned char* nxt = smem + ((step + 1) & 1) * kWgStageBytes;
+    const bool more = step + 1 < n_steps;
+    if (more) {          // next slab: global -> registers, in flight under this step's MFMAs
+#pragma unroll
+      for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const bf16x8*>(ga[u] + (long)(step + 1) * astep);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) rb[u] = *reinterpret_cast<const bf16x8*>(gb[u] + (long)(step + 1) * bstep);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[2], bfr[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const unsigned char* base = cur + a_tile + fo[a] + s * 2048;
+        const bf16x4 lo = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base)));
+        const bf16x4 hi = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 1024)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { af[a][j] = lo[j]; af[a][4 + j] = hi[j]; }
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const unsigned char* base = cur + b_tile + (b >> 1) * 4096 + fo[b & 1] + s * 2048;
+        const bf16x4 lo = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base)));
+        const bf16x4 hi = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 1024)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bfr[b][j] = lo[j]; bfr[b][4 + j] = hi[j]; }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) *reinterpret_cast<bf16x8*>(nxt + la[u]) = ra[u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) *reinterpret_cast<bf16x8*>(nxt + lb[u]) = rb[u];
+    }
+    __syncthreads();     // nxt is complete, cur is free (one barrier per step: writes go to the other buffer)
+  }
+
+  // ---- epilogue: dW[m][n] += acc   (accumulator register i of lane (r,h): row kap(i,h), col r) ----
+  if (p.slabs) {
+    float* out = p.slabs + (long)ks * p.M * p.N + (long)(m0 + (wave & 1) * 64) * p.N + n0 + (wave >> 1) * 128 + r;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          out[(long)(32 * a + kap(i, h)) * p.N + 32 * b] = acc[a][b][i];
+    return;
+  }
+  float* out = p.dw + (long)(m0 + (wave & 1) * 64) * p.ldw + n0 + (wave >> 1) * 128 + r;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        atomicAdd(out + (long)(32 * a + kap(i, h)) * p.ldw + 32 * b, acc[a][b][i]);
+}
+
+// dw[m][n] += sum_s slabs[s][m][n]   (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* dw, long ldw, const float* slabs, int split, int M, int N) {
+  const long n4 = (long)M * N / 4;
+  for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < n4; c += (long)gridDim.x * 256) {
+    const long e = c * 4;
+    const int m = (int)(e / N), n = (int)(e - (long)m * N);
+    f32x4 a = *reinterpret_cast<const f32x4*>(dw + (long)m * ldw + n);
+    for (int s2 = 0; s2 < split; ++s2) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(slabs + (long)s2 * M * N + e);
+      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    *reinterpret_cast<f32x4*>(dw + (long)m * ldw + n) = a;
+  }
+}
+
+}  // namespace mmt
+
+namespace {
+// split-K factor: one full round of workgroups (2 per CU), slices of >= 256 rows
+int wgrad_split(int tiles, long K) {
+  int split = 512 / tiles;
+  const int max_split = (int)((K + 255) / 256);
+  if (split > max_split) split = max_split;
+  return split < 1 ? 1 : split;
+}
+}  // namespace
+
+extern "C" size_t mmt_wgrad_workspace_bytes(int32_t M, int32_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0 || (M % mmt::kWgTM) || (N % mmt::kWgTN)) return 0;
+  return (size_t)wgrad_split((M / mmt::kWgTM) * (N / mmt::kWgTN), K) * M * N * sizeof(float);
+}
+
+extern "C" int mmt_wgrad_accumulate(float* dw, int64_t ldw, const void* dy, int64_t ldy, const void* x,
+                                    int64_t ldx, int32_t M, int32_t N, int64_t K, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  if (!dw || !dy || !x) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: NULL argument");
+  if (M <= 0 || N <= 0 || K <= 0 || (M % mmt::kWgTM) || (N % mmt::kWgTN) || (K % 32))
+    return mmt::fail(MMT_E_UNSUPPORTED, "mmt_wgrad_accumulate: needs M %% 128 == 0, N %% 256 == 0, K %% 32 == 0 (got %d, %d, %lld)", M, N, (long long)K);
+  if ((ldy % 8) || (ldx % 8) || ldy < M || ldx < N || ldw < N || (ldw % 4)) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: bad leading dimensions");
+  if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)dw & 15)) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: operands must be 16-byte aligned");
+  mmt::WgradParams p;
+  p.dy = (const __bf16*)dy; p.x = (const __bf16*)x; p.dw = dw;
+  p.ldy = ldy; p.ldx = ldx; p.ldw = ldw; p.M = M; p.N = N; p.K = (int)K;
+  const int tiles_m = M / mmt::kWgTM;
+  p.tiles_n = N / mmt::kWgTN;
+  const int tiles = tiles_m * p.tiles_n;
+  int split = wgrad_split(tiles, K);
+  const int kps = (int)(((K + split - 1) / split + 31) / 32 * 32);
+  split = (int)((K + kps - 1) / kps);
+  p.k_per_split = kps;
+  const size_t need = (size_t)split * M * N * sizeof(float);
+  p.slabs = (workspace && workspace_bytes >= need && split > 1) ? (float*)workspace : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  const int lds = 2 * mmt::kWgStageBytes;
+  hipLaunchKernelGGL(mmt::wgrad_kernel, dim3(tiles, split), dim3(256), lds, st, p);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess && p.slabs) {
+    long blocks = ((long)M * N / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mmt::wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw, (long)ldw, p.slabs, split, M, N);
+    e = hipGetLastError();
+  }
+  return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_wgrad_accumulate: %s", hipGetErrorString(e));
+}

@@ -22,7 +22,7 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
            'mmt_attn_bwd', 'mmt_side_inputs',
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
-           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_accumulate_grad', 'mmt_adamw_step')
+           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_accumulate_grad', 'mmt_adamw_step', 'mmt_wgrad_accumulate', 'mmt_wgrad_workspace_bytes')
 
 
 class RowsDesc(ctypes.Structure):
@@ -115,6 +115,11 @@ def lib() -> ctypes.CDLL:
   L.mmt_ln_bwd.argtypes = [rd] + [vp] * 9 + [ctypes.c_size_t, vp]
   L.mmt_residual_block_bwd.argtypes = [rd] + [vp] * 12 + [ctypes.c_size_t, vp]
   L.mmt_bias_gelu_bwd.argtypes = [rd] + [vp] * 6 + [ctypes.c_size_t, vp]
+  L.mmt_wgrad_accumulate.restype = ctypes.c_int
+  L.mmt_wgrad_accumulate.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int32,
+                                     ctypes.c_int32, ctypes.c_int64, vp, ctypes.c_size_t, vp]
+  L.mmt_wgrad_workspace_bytes.restype = ctypes.c_size_t
+  L.mmt_wgrad_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]
   L.mmt_adamw_step.restype = ctypes.c_int
   L.mmt_adamw_step.argtypes = [ctypes.POINTER(AdamwDesc)] + [vp] * 8
   L.mmt_accumulate_grad.restype = ctypes.c_int

@@ -228,3 +228,35 @@ def accumulate_grad_(acc: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
   with torch.cuda.device(acc.device):
     _lib.check(_lib.lib().mmt_accumulate_grad(acc.data_ptr(), g.data_ptr(), code, acc.numel(), _stream(acc)))
   return acc
+
+
+def wgrad_accumulate_(dw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor) -> bool:
+  """dw (fp32 [M,N]) += dy[K,M]^T @ x[K,N] (bf16) with the hand-written split-K kernel.
+  Returns False (nothing done) when the shape/layout is outside what the kernel is built for."""
+  K, M = dy.shape
+  N = x.shape[1]
+  ok = (dw.is_cuda and dw.dtype == torch.float32 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+        and dw.shape == (M, N) and x.shape[0] == K and M % 128 == 0 and N % 256 == 0 and K % 32 == 0
+        and dw.stride(1) == 1 and dy.stride(1) == 1 and x.stride(1) == 1
+        and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+        and dw.stride(0) % 4 == 0 and dw.data_ptr() % 16 == 0)
+  if not ok:
+    return False
+  L = _lib.lib()
+  ws = _wgrad_ws(dw.device, L.mmt_wgrad_workspace_bytes(M, N, K))
+  with torch.cuda.device(dw.device):
+    _lib.check(L.mmt_wgrad_accumulate(dw.data_ptr(), dw.stride(0), dy.data_ptr(), dy.stride(0),
+                                      x.data_ptr(), x.stride(0), M, N, K, ws.data_ptr(), ws.numel(), _stream(dw)))
+  return True
+
+
+_WGRAD_WS = {}
+
+
+def _wgrad_ws(device, nbytes):
+  """One grow-only scratch buffer per device for the split-K slabs (stream-ordered reuse)."""
+  buf = _WGRAD_WS.get(device)
+  if buf is None or buf.numel() < nbytes:
+    buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=device)
+    _WGRAD_WS[device] = buf
+  return buf

@@ -72,8 +72,61 @@ def cast_param(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
   return _CastParamFn.apply(param, dtype)
 
 
+def _param_weight(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+  shadow = getattr(param, '_mmt_shadow', None)
+  return shadow if (shadow is not None and shadow.dtype == dtype) else param.detach().to(dtype)
+
+
+def _notify(param):
+  for hook in getattr(param, '_mmt_grad_ready_hooks', ()):
+    hook(param)
+
+
+class _LinearFn(torch.autograd.Function):
+  """y = x @ W^T (+ b) with fp32 master parameters and bf16 compute.  Backward: dx by a library
+  GEMM; dW by the hand-written split-K kernel `mmt_wgrad_accumulate`, accumulated in fp32
+  straight into `weight.grad` (library GEMM + accumulate kernel when the shape is outside what
+  the kernel is built for); db as an fp32 column sum into `bias.grad`."""
+
+  @staticmethod
+  def forward(ctx, x, weight, bias):
+    w = _param_weight(weight, x.dtype)
+    b = None if bias is None else _param_weight(bias, x.dtype)
+    ctx.save_for_backward(x, w)
+    ctx.params = (weight, bias)
+    return F.linear(x, w, b)
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    weight, bias = ctx.params
+    dy2 = dy.reshape(-1, dy.shape[-1])
+    x2 = x.reshape(-1, x.shape[-1])
+    if not dy2.is_contiguous():
+      dy2 = dy2.contiguous()
+    dx = torch.mm(dy2, w).view(x.shape) if ctx.needs_input_grad[0] else None
+    if weight.requires_grad:
+      if weight.grad is None:
+        weight.grad = torch.zeros_like(weight, dtype=torch.float32)
+      if not (weight.grad.dtype == torch.float32 and fused.wgrad_accumulate_(weight.grad, dy2, x2)):
+        fused.accumulate_grad_(weight.grad, torch.mm(dy2.t(), x2)) if weight.grad.dtype == torch.float32 \
+            else weight.grad.add_(torch.mm(dy2.t(), x2))
+      _notify(weight)
+    if bias is not None and bias.requires_grad:
+      db = dy2.sum(0, dtype=torch.float32)
+      if bias.grad is None:
+        bias.grad = db.to(bias.dtype)
+      else:
+        bias.grad.add_(db)
+      _notify(bias)
+    return dx, None, None
+
+
 def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
   """x @ W^T + b in x's dtype (fp32 master weights, bf16 compute)."""
+  if (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled() and isinstance(weight, nn.Parameter)
+      and weight.dtype == torch.float32 and (bias is None or isinstance(bias, nn.Parameter))):
+    return _LinearFn.apply(x, weight, bias)
   return F.linear(x, cast_param(weight, x.dtype), None if bias is None else cast_param(bias, x.dtype))
 
 

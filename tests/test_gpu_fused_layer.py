@@ -158,3 +158,40 @@ def test_fused_adamw_matches_torch_adamw():
       assert float((pr - po).abs().max()) < 2e-6, (step, n)
       assert torch.equal(po._mmt_shadow, po.detach().to(torch.bfloat16)), n
       assert float(po.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('K,M,N', [(64, 128, 256), (4096, 768, 768), (2048, 2304, 768), (1024, 768, 3072), (96, 256, 512)])
+@pytest.mark.parametrize('use_ws', [True, False])
+def test_wgrad_accumulate(K, M, N, use_ws):
+  """dW += dY^T X (split-K MFMA kernel, fp32 accumulate) vs an fp64 torch product."""
+  from mmt_amd import _lib, fused
+  torch.manual_seed(K + M)
+  dy = torch.randn(K, M, device='cuda').to(torch.bfloat16)
+  x = torch.randn(K, N, device='cuda').to(torch.bfloat16)
+  dw0 = torch.randn(M, N, device='cuda')
+  dw = dw0.clone()
+  if use_ws:
+    assert fused.wgrad_accumulate_(dw, dy, x)
+  else:   # no workspace: float-atomic epilogue
+    _lib.check(_lib.lib().mmt_wgrad_accumulate(dw.data_ptr(), N, dy.data_ptr(), M, x.data_ptr(), N, M, N, K, None, 0,
+                                               torch.cuda.current_stream().cuda_stream))
+  want = dw0.double() + dy.double().t() @ x.double()
+  err = float((dw.double() - want).abs().max()) / float(want.abs().max())
+  assert err < 2e-5, err
+  assert not fused.wgrad_accumulate_(dw, dy[:, :100].contiguous(), x)       # unsupported shape -> caller falls back
+
+
+def test_linear_fn_matches_autograd():
+  from mmt_amd import layers
+  torch.manual_seed(0)
+  w = torch.nn.Parameter(torch.randn(256, 512, device='cuda') * 0.05)
+  b = torch.nn.Parameter(torch.randn(256, device='cuda') * 0.05)
+  x = torch.randn(4, 64, 512, device='cuda', dtype=torch.bfloat16, requires_grad=True)
+  g = torch.randn(4, 64, 256, device='cuda', dtype=torch.bfloat16)
+  layers._linear(x, w, b).backward(g)
+  x2 = x.detach().clone().requires_grad_(True)
+  w2, b2 = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+  torch.nn.functional.linear(x2, w2.to(torch.bfloat16), b2.to(torch.bfloat16)).backward(g)
+  assert float((x.grad.float() - x2.grad.float()).abs().max()) < 1e-2
+  assert float((w.grad - w2.grad).abs().max()) / float(w2.grad.abs().max()) < 1e-2     # autograd's dW is bf16-rounded
+  assert float((b.grad - b2.grad).abs().max()) / float(b2.grad.abs().max()) < 1e-2
