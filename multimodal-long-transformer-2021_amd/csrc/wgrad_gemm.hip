@@ -20,7 +20,12 @@
 
 namespace mmt {
 
-constexpr int kWgTM = 128, kWgTN = 256, kWgStageBytes = (kWgTM + kWgTN) * 32 * 2;   // 24 KiB
+constexpr int kWgTN = 256;
+// MW = wave rows along M: workgroup = 2*MW waves, tile (64*MW) x 256
+template <int MW> struct WgCfg {
+  static constexpr int kTM = 64 * MW, kThreads = 128 * MW, kBPer = 8 / MW;
+  static constexpr int kStageBytes = (kTM + kWgTN) * 32 * 2;
+};
 
 struct WgradParams {
   const __bf16* dy;   // [K, M] row stride ldy
@@ -36,7 +41,10 @@ __device__ __forceinline__ int vtile_off(int row, int ch) {      // byte offset 
   return row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+template <int MW>
+__global__ __launch_bounds__(128 * MW, 2) void wgrad_kernel(const WgradParams p) {
+  using C = WgCfg<MW>;
+  constexpr int kWgTM = C::kTM, kWgStageBytes = C::kStageBytes;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -51,17 +59,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 
   // ---- staging map: 16-byte chunks; A slab 32 x 128 cols = 512 chunks (2 per thread),
   //      B slab 32 x 256 cols = 1024 chunks (4 per thread) -------------------------------------
+  constexpr int kAChunksRow = kWgTM / 8;      // 16-byte chunks per A-slab row
   const __bf16* ga[2]; int la[2];
-  const __bf16* gb[4]; int lb[4];
+  const __bf16* gb[C::kBPer]; int lb[C::kBPer];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int c = tid + 256 * u, row = c >> 4, ch = c & 15;
+    const int c = tid + C::kThreads * u, row = c / kAChunksRow, ch = c % kAChunksRow;
     ga[u] = p.dy + (long)(k_begin + row) * p.ldy + m0 + ch * 8;
     la[u] = (ch >> 3) * 4096 + vtile_off(row, ch & 7);
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int c = tid + 256 * u, row = c >> 5, ch = c & 31;
+  for (int u = 0; u < C::kBPer; ++u) {
+    const int c = tid + C::kThreads * u, row = c >> 5, ch = c & 31;
     gb[u] = p.x + (long)(k_begin + row) * p.ldx + n0 + ch * 8;
     lb[u] = kWgTM * 64 + (ch >> 3) * 4096 + vtile_off(row, ch & 7);
   }
@@ -72,8 +81,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
   int fo[2];      // column block db = 0/1 inside a tile
 #pragma unroll
   for (int db = 0; db < 2; ++db) fo[db] = frow * 128 + ((db ^ ((frow >> 1) & 1)) << 6) + 32 * cb + 8 * (li & 3);
-  const int a_tile = (wave & 1) * 4096;                              // this wave's 64 M columns
-  const int b_tile = kWgTM * 64 + (wave >> 1) * 2 * 4096;            // this wave's 128 N columns
+  const int wm = wave % MW, wn = wave / MW;
+  const int a_tile = wm * 4096;                                  // this wave's 64 M columns
+  const int b_tile = kWgTM * 64 + wn * 2 * 4096;                 // this wave's 128 N columns
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -81,15 +91,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x16{0};
 
-  bf16x8 ra[2], rb[4];
+  bf16x8 ra[2], rb[C::kBPer];
 #pragma unroll
   for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const bf16x8*>(ga[u]);
 #pragma unroll
-  for (int u = 0; u < 4; ++u) rb[u] = *reinterpret_cast<const bf16x8*>(gb[u]);
+  for (int u = 0; u < C::kBPer; ++u) rb[u] = *reinterpret_cast<const bf16x8*>(gb[u]);
 #pragma unroll
   for (int u = 0; u < 2; ++u) *reinterpret_cast<bf16x8*>(smem + la[u]) = ra[u];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) *reinterpret_cast<bf16x8*>(smem + lb[u]) = rb[u];
+  for (int u = 0; u < C::kBPer; ++u) *reinterpret_cast<bf16x8*>(smem + lb[u]) = rb[u];
   __syncthreads();
 
   for (int step = 0; step < n_steps; ++step) {
@@ -100,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const bf16x8*>(ga[u] + (long)(step + 1) * astep);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) rb[u] = *reinterpret_cast<const bf16x8*>(gb[u] + (long)(step + 1) * bstep);
+      for (int u = 0; u < C::kBPer; ++u) rb[u] = *reinterpret_cast<const bf16x8*>(gb[u] + (long)(step + 1) * bstep);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -131,14 +141,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) *reinterpret_cast<bf16x8*>(nxt + la[u]) = ra[u];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) *reinterpret_cast<bf16x8*>(nxt + lb[u]) = rb[u];
+      for (int u = 0; u < C::kBPer; ++u) *reinterpret_cast<bf16x8*>(nxt + lb[u]) = rb[u];
     }
     __syncthreads();     // nxt is complete, cur is free (one barrier per step: writes go to the other buffer)
   }
 
   // ---- epilogue: dW[m][n] += acc   (accumulator register i of lane (r,h): row kap(i,h), col r) ----
   if (p.slabs) {
-    float* out = p.slabs + (long)ks * p.M * p.N + (long)(m0 + (wave & 1) * 64) * p.N + n0 + (wave >> 1) * 128 + r;
+    float* out = p.slabs + (long)ks * p.M * p.N + (long)(m0 + wm * 64) * p.N + n0 + wn * 128 + r;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
           out[(long)(32 * a + kap(i, h)) * p.N + 32 * b] = acc[a][b][i];
     return;
   }
-  float* out = p.dw + (long)(m0 + (wave & 1) * 64) * p.ldw + n0 + (wave >> 1) * 128 + r;
+  float* out = p.dw + (long)(m0 + wm * 64) * p.ldw + n0 + wn * 128 + r;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -176,9 +186,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* dw, long ldw, 
 }  // namespace mmt
 
 namespace {
-// split-K factor: one full round of workgroups (2 per CU), slices of >= 256 rows
-int wgrad_split(int tiles, long K) {
-  int split = 512 / tiles;
+// 256-row tiles (8 waves, one workgroup per CU) when M allows, else 128-row tiles (4 waves, 2 per CU)
+int wgrad_tile_m(int M) { return (M % 256) == 0 ? 256 : 128; }
+// split-K factor: one full round of workgroups, slices of >= 256 rows
+int wgrad_split(int tiles, long K, int tile_m) {
+  int split = (tile_m == 256 ? 256 : 512) / tiles;
   const int max_split = (int)((K + 255) / 256);
   if (split > max_split) split = max_split;
   return split < 1 ? 1 : split;
@@ -186,33 +198,40 @@ int wgrad_split(int tiles, long K) {
 }  // namespace
 
 extern "C" size_t mmt_wgrad_workspace_bytes(int32_t M, int32_t N, int64_t K) {
-  if (M <= 0 || N <= 0 || K <= 0 || (M % mmt::kWgTM) || (N % mmt::kWgTN)) return 0;
-  return (size_t)wgrad_split((M / mmt::kWgTM) * (N / mmt::kWgTN), K) * M * N * sizeof(float);
+  if (M <= 0 || N <= 0 || K <= 0 || (M % 128) || (N % mmt::kWgTN)) return 0;
+  const int tm = wgrad_tile_m(M);
+  return (size_t)wgrad_split((M / tm) * (N / mmt::kWgTN), K, tm) * M * N * sizeof(float);
 }
 
 extern "C" int mmt_wgrad_accumulate(float* dw, int64_t ldw, const void* dy, int64_t ldy, const void* x,
                                     int64_t ldx, int32_t M, int32_t N, int64_t K, void* workspace,
                                     size_t workspace_bytes, void* stream) {
   if (!dw || !dy || !x) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: NULL argument");
-  if (M <= 0 || N <= 0 || K <= 0 || (M % mmt::kWgTM) || (N % mmt::kWgTN) || (K % 32))
+  if (M <= 0 || N <= 0 || K <= 0 || (M % 128) || (N % mmt::kWgTN) || (K % 32))
     return mmt::fail(MMT_E_UNSUPPORTED, "mmt_wgrad_accumulate: needs M %% 128 == 0, N %% 256 == 0, K %% 32 == 0 (got %d, %d, %lld)", M, N, (long long)K);
   if ((ldy % 8) || (ldx % 8) || ldy < M || ldx < N || ldw < N || (ldw % 4)) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: bad leading dimensions");
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)dw & 15)) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: operands must be 16-byte aligned");
   mmt::WgradParams p;
   p.dy = (const __bf16*)dy; p.x = (const __bf16*)x; p.dw = dw;
   p.ldy = ldy; p.ldx = ldx; p.ldw = ldw; p.M = M; p.N = N; p.K = (int)K;
-  const int tiles_m = M / mmt::kWgTM;
+  const int tile_m = wgrad_tile_m(M);
+  const int tiles_m = M / tile_m;
   p.tiles_n = N / mmt::kWgTN;
   const int tiles = tiles_m * p.tiles_n;
-  int split = wgrad_split(tiles, K);
+  int split = wgrad_split(tiles, K, tile_m);
   const int kps = (int)(((K + split - 1) / split + 31) / 32 * 32);
   split = (int)((K + kps - 1) / kps);
   p.k_per_split = kps;
   const size_t need = (size_t)split * M * N * sizeof(float);
   p.slabs = (workspace && workspace_bytes >= need && split > 1) ? (float*)workspace : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  const int lds = 2 * mmt::kWgStageBytes;
-  hipLaunchKernelGGL(mmt::wgrad_kernel, dim3(tiles, split), dim3(256), lds, st, p);
+  if (tile_m == 256) {
+    const int lds = 2 * mmt::WgCfg<4>::kStageBytes;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmt::wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(mmt::wgrad_kernel<4>, dim3(tiles, split), dim3(512), lds, st, p);
+  } else {
+    hipLaunchKernelGGL(mmt::wgrad_kernel<2>, dim3(tiles, split), dim3(256), 2 * mmt::WgCfg<2>::kStageBytes, st, p);
+  }
   hipError_t e = hipGetLastError();
   if (e == hipSuccess && p.slabs) {
     long blocks = ((long)M * N / 4 + 255) / 256;
