@@ -51,6 +51,7 @@ enum {
 
 /* flags */
 #define MMT_FLAG_SCALE_BEFORE_ADD 1u /* s = content*scale + rel  (default: (content+rel)*scale) */
+#define MMT_FLAG_ACCUM_REL_GRADS 2u  /* backward: drel_emb / drel_bias += (fp32 master gradients) instead of = */
 
 /* Attention pattern + id generator.  With local_radius >= S and n_global == 0 the
  * pattern is exactly the reference's segmented mask (data_utils.py:321-322):
@@ -111,7 +112,8 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
                  size_t workspace_bytes, void* stream);
 
 /* Backward of the same operator.  dq,dk,dv in desc->dtype with q/k/v strides;
- * drel_emb [R,N,D] and drel_bias [R,N] are fp32 and are OVERWRITTEN (not accumulated).
+ * drel_emb [R,N,D] and drel_bias [R,N] are fp32 and are OVERWRITTEN, or added to when
+ * desc->flags has MMT_FLAG_ACCUM_REL_GRADS (gradient accumulation into the master gradients).
  * drel_bias / drel_emb may be NULL when R == 0. */
 int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const void* v,
                  const void* rel_emb, const void* rel_bias, const int32_t* att_mask,

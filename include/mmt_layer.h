@@ -109,6 +109,12 @@ size_t mmt_wgrad_workspace_bytes(int32_t M, int32_t N, int64_t K);
 int mmt_wgrad_accumulate(float* dw, int64_t ldw, const void* dy, int64_t ldy, const void* x,
                          int64_t ldx, int32_t M, int32_t N, int64_t K, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* Same, and additionally dbias[M] += column sums of dy (the Dense layer's bias gradient, fp32): the
+ * workgroups of the first column tile add up the dy chunks they stage for the product anyway.
+ * dbias == NULL: exactly mmt_wgrad_accumulate. */
+int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, const void* dy, int64_t ldy,
+                              const void* x, int64_t ldx, int32_t M, int32_t N, int64_t K,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
         acc = fmaf(of.v[s], dof.v[s], acc);
       }
     }
-    delta = acc + half_xchg(acc);
+    delta = half_sum(acc);
   }
   const long row_id = ((long)b * p.N + n) * p.S + qc;
   if (!split_item && q_ok && h == 0) p.delta[row_id] = delta;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
     else mma_xt(a0, a1, kcur, xlds, g, lane);
   }
   if (!IDENT && p.pat.id_mode == 1) {       // flush the clipped columns (both halves of the row)
-    const float fn = far_neg + half_xchg(far_neg), fp = far_pos + half_xchg(far_pos);
+    const float fn = half_sum(far_neg), fp = half_sum(far_pos);
     if (h == 0) {
       if (p.pat.m == 0) dtrow[0] = fn + fp;
       else { dtrow[0] = fn; dtrow[2 * p.pat.m] = fp; }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
           vals[i] = use ? dtab[kap(i, h) * kTStride(Rp) + col] : 0.f;
           bsum += vals[i];
         }
-        bsum += half_xchg(bsum);
+        bsum = half_sum(bsum);
         f32x16 e0 = {0}, e1 = {0};
         mma_xt_hilo(e0, e1, qt, xlds, vals, lane);
         float* row = pe + (long)id * 64;
@@ -622,8 +622,12 @@ __global__ __launch_bounds__(1024) void drel_reduce_kernel(const BwdParams p) {
   if (part == 0) {
     float a = 0.f, bsum = 0.f;
     for (int j = 0; j < 16; ++j) { a += red[j][d]; bsum += redb[j]; }
-    p.drel_emb[((long)id * p.N + n) * 64 + d] = a;
-    if (d == 0 && p.drel_bias) p.drel_bias[(long)id * p.N + n] = bsum;
+    float* de = p.drel_emb + ((long)id * p.N + n) * 64 + d;
+    *de = p.drel_accum ? *de + a : a;
+    if (d == 0 && p.drel_bias) {
+      float* db = p.drel_bias + (long)id * p.N + n;
+      *db = p.drel_accum ? *db + bsum : bsum;
+    }
   }
 }
 

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc = fmaf((float)of.v[s][j], (float)dof.v[s][j], acc);
-    delta = acc + half_xchg(acc);
+    delta = half_sum(acc);
   }
   const long row_id = ((long)b * p.N + n) * p.S + min(q, p.S - 1);
   if (!split_item && q_ok && h == 0) p.delta[row_id] = delta;
@@ -259,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
 #pragma unroll
   for (int i = 0; i < 16; ++i) { a0[i] *= p.gscale; a1[i] *= p.gscale; }
   if (HAS_REL) {
-    const float fn = (far_neg_acc + half_xchg(far_neg_acc)) * p.rel_gscale;
-    const float fp = (far_pos_acc + half_xchg(far_pos_acc)) * p.rel_gscale;
+    const float fn = half_sum(far_neg_acc) * p.rel_gscale;
+    const float fp = half_sum(far_pos_acc) * p.rel_gscale;
     if (h == 0) {
       if (m == 0) dtrow[0] = fn + fp;
       else { dtrow[0] = fn; dtrow[2 * m] = fp; }
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
           vals[i] = use ? dtab[kap(i, h) * kTStride(Rp) + col] : 0.f;
           bsum += vals[i];
         }
-        bsum += half_xchg(bsum);
+        bsum = half_sum(bsum);
         f32x16 e0 = {0}, e1 = {0};
         mma_xt_hilo(e0, e1, VTile<T>{}, xlds, vals, lane);
         float* row = pe + (long)id * 64;

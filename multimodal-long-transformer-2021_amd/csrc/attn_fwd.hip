@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
         tmax = fmaxf(tmax, s);
       }
     }
-    tmax = fmaxf(tmax, half_xchg(tmax));
+    tmax = half_max(tmax);
     // Deferred rescale: the running reference m_run only moves when some row's tile maximum
     // exceeds it by more than kRescaleThr (log2 units), so p stays <= 2^kRescaleThr; O, l and
     // p always share one reference, hence the normalised result is unchanged.
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
   }
 
   // ---- epilogue --------------------------------------------------------------------------
-  const float l_tot = l_run + half_xchg(l_run);
+  const float l_tot = half_sum(l_run);
   if (rows_item) {
     // partial, unnormalised: part_o[bn][rowblk][chunk][q 32][d 64], part_ml[...][2][32]
     const long slot = ((long)bn * p.n_rowblk + rowblk) * p.n_chunks + chunk;

@@ -168,27 +168,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
     const float relc = HAS_REL ? (far_neg ? relfn : relfp) : 0.f;
     const int dbase = k0 - q + 4 * h;
 
-    float pr[16];
-    if (plain && one_id) {                                     // ---- class A
+    float pr[16], s2[16];
+    const bool cls_a = plain && one_id;
+    float tmax;
+    if (cls_a) {                                               // ---- class A
       float cm = fmaxf(fmaxf(c[0], c[1]), c[2]);
 #pragma unroll
       for (int i = 3; i < 15; i += 2) cm = fmaxf(fmaxf(cm, c[i]), c[i + 1]);
       cm = fmaxf(cm, c[15]);
-      float tmax = fmaf(cm, p.sscale, relc);
-      tmax = fmaxf(tmax, half_xchg(tmax));
-      if (__any(tmax > m_run + kRescaleThr)) {
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-      }
-      const float rc = relc - m_run;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rc));
+      tmax = fmaf(cm, p.sscale, relc);
     } else {
-      float s2[16];
       if (plain) {                                             // ---- class B (HAS_REL, mixed ids)
         const int abase = trow_addr + 4 * (m + dbase), alo = trow_addr, ahi = trow_addr + 8 * m;
 #pragma unroll
@@ -222,19 +211,25 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
           s2[i] = kk < p.S ? s : -INFINITY;
         }
       }
-      float tmax = fmaxf(fmaxf(s2[0], s2[1]), s2[2]);
+      tmax = fmaxf(fmaxf(s2[0], s2[1]), s2[2]);
 #pragma unroll
       for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s2[i]), s2[i + 1]);
       tmax = fmaxf(tmax, s2[15]);
-      tmax = fmaxf(tmax, half_xchg(tmax));
-      if (__any(tmax > m_run + kRescaleThr)) {
-        const float m_new = fmaxf(m_run, tmax);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        m_run = m_new;
-        l_run *= alpha;
+    }
+    tmax = half_max(tmax);
+    if (__any(tmax > m_run + kRescaleThr)) {                   // deferred rescale, one site
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
-      }
+      for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+    }
+    if (cls_a) {
+      const float rc = relc - m_run;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rc));
+    } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(s2[i] - m_run);
     }
@@ -256,7 +251,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------
-  const float l_tot = l_run + half_xchg(l_run);
+  const float l_tot = half_sum(l_run);
   if (rows_item) {
     const long slot = ((long)bn * p.n_rowblk + rowblk) * p.n_chunks + chunk;
     float* po = p.part_o + slot * (32 * 64) + r * 64;

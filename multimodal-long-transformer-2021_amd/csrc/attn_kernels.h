@@ -43,6 +43,7 @@ struct BwdParams {
   const int32_t* valid_len;
   void *dq, *dk, *dv;
   float *drel_emb, *drel_bias;        // outputs [R,N,64], [R,N] fp32
+  int drel_accum;                     // != 0: add to them instead of overwriting
   int B, S, N, R, Rp;
   long qs[3], ks[3], vs[3], os[3];    // q/dq, k/dk, v/dv, out/dout
   float sscale, tscale, mask_add;     // as FwdParams (log2 domain)

@@ -87,6 +87,15 @@ __device__ __forceinline__ void frag_from_tile(Frag<__bf16>& f, const unsigned c
 }
 
 __device__ __forceinline__ float half_xchg(float x) { return __shfl_xor(x, 32, 64); }
+// Reductions over the lane pair (l, l ^ 32) with gfx950's v_permlane32_swap: after the swap
+// `a` holds the low half's value and `b` the high half's in every lane -- one VALU op and no LDS
+// round trip (ds_bpermute) in the per-tile dependency chain.
+__device__ __forceinline__ void half_pair(float x, float& a, float& b) {
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float half_max(float x) { float a, b; half_pair(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float half_sum(float x) { float a, b; half_pair(x, a, b); return a + b; }
 
 constexpr int kTStride(int Rp) { return Rp + 1; }
 constexpr float kRescaleThr = 6.0f;

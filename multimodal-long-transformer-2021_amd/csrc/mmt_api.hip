@@ -209,6 +209,7 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   p.sscale = f.sscale; p.tscale = f.tscale; p.mask_add = f.mask_add;
   p.gscale = desc->scale;
   p.rel_gscale = (desc->flags & MMT_FLAG_SCALE_BEFORE_ADD) ? 1.f : desc->scale;
+  p.drel_accum = (desc->flags & MMT_FLAG_ACCUM_REL_GRADS) ? 1 : 0;
   p.pat = f.pat;
   if (desc->R == 0) { p.pat.id_mode = 0; p.rel_ids = nullptr; }
   p.perm_1d = (!dense && p.pat.id_mode == MMT_IDS_1D && desc->R >= 2 * p.pat.m + 1) ? 1 : 0;

@@ -32,6 +32,8 @@ struct WgradParams {
   const __bf16* x;    // [K, N] row stride ldx
   float* dw;          // [M, N] row stride ldw (fp32, accumulated into)
   float* slabs;       // [split, M, N] fp32 partials (plain stores) or NULL -> float atomics into dw
+  float* dbias;       // [M] fp32 += column sums of dy (NULL: not wanted); written by the tn == 0 tiles
+  float* bias_part;   // [split, M] partial column sums (slab mode) or NULL -> float atomics into dbias
   long ldy, ldx, ldw;
   int M, N, K;
   int tiles_n, k_per_split;   // rows per split-K slice (multiple of 32)
@@ -90,6 +92,16 @@ __global__ __launch_bounds__(128 * MW, 2) void wgrad_kernel(const WgradParams p)
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x16{0};
+  // bias gradient = column sums of dy: the tn == 0 workgroups add up the dy chunks they stage anyway
+  // (VALU work beside an LDS/MFMA-bound loop); thread -> fixed 8 columns, rows tid/kAChunksRow (+16)
+  const bool do_bias = p.dbias != nullptr && tn == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto add_bias = [&](const bf16x8 (&ra_)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bsum[j] += (float)ra_[u][j];
+  };
 
   bf16x8 ra[2], rb[C::kBPer];
 #pragma unroll
@@ -100,6 +112,7 @@ __global__ __launch_bounds__(128 * MW, 2) void wgrad_kernel(const WgradParams p)
   for (int u = 0; u < 2; ++u) *reinterpret_cast<bf16x8*>(smem + la[u]) = ra[u];
 #pragma unroll
   for (int u = 0; u < C::kBPer; ++u) *reinterpret_cast<bf16x8*>(smem + lb[u]) = rb[u];
+  if (do_bias) add_bias(ra);
   __syncthreads();
 
   for (int step = 0; step < n_steps; ++step) {
@@ -142,8 +155,24 @@ __global__ __launch_bounds__(128 * MW, 2) void wgrad_kernel(const WgradParams p)
       for (int u = 0; u < 2; ++u) *reinterpret_cast<bf16x8*>(nxt + la[u]) = ra[u];
 #pragma unroll
       for (int u = 0; u < C::kBPer; ++u) *reinterpret_cast<bf16x8*>(nxt + lb[u]) = rb[u];
+      if (do_bias) add_bias(ra);
     }
     __syncthreads();     // nxt is complete, cur is free (one barrier per step: writes go to the other buffer)
+  }
+
+  if (do_bias) {       // 16 row groups x kWgTM columns through the (now idle) staging LDS, fixed order
+    float* red = reinterpret_cast<float*>(smem);
+    const int grp = tid / kAChunksRow, ch = tid % kAChunksRow;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[grp * kWgTM + ch * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < kWgTM) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g * kWgTM + tid];
+      if (p.bias_part) p.bias_part[(long)ks * p.M + m0 + tid] = t;
+      else atomicAdd(p.dbias + m0 + tid, t);
+    }
   }
 
   // ---- epilogue: dW[m][n] += acc   (accumulator register i of lane (r,h): row kap(i,h), col r) ----
@@ -169,8 +198,17 @@ __global__ __launch_bounds__(128 * MW, 2) void wgrad_kernel(const WgradParams p)
 }
 
 // dw[m][n] += sum_s slabs[s][m][n]   (fixed order: bitwise reproducible)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* dw, long ldw, const float* slabs, int split, int M, int N) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* dw, long ldw, const float* slabs, int split, int M, int N,
+                                                           float* dbias, const float* bias_part) {
   const long n4 = (long)M * N / 4;
+  if (dbias) {           // bias partials: one column per thread, independent loads
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < M; c += gridDim.x * 256) {
+      float a = dbias[c];
+#pragma unroll 8
+      for (int s2 = 0; s2 < split; ++s2) a += bias_part[(long)s2 * M + c];
+      dbias[c] = a;
+    }
+  }
   for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < n4; c += (long)gridDim.x * 256) {
     const long e = c * 4;
     const int m = (int)(e / N), n = (int)(e - (long)m * N);
@@ -200,12 +238,18 @@ int wgrad_split(int tiles, long K, int tile_m) {
 extern "C" size_t mmt_wgrad_workspace_bytes(int32_t M, int32_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0 || (M % 128) || (N % mmt::kWgTN)) return 0;
   const int tm = wgrad_tile_m(M);
-  return (size_t)wgrad_split((M / tm) * (N / mmt::kWgTN), K, tm) * M * N * sizeof(float);
+  return (size_t)wgrad_split((M / tm) * (N / mmt::kWgTN), K, tm) * ((size_t)M * N + M) * sizeof(float);
 }
 
 extern "C" int mmt_wgrad_accumulate(float* dw, int64_t ldw, const void* dy, int64_t ldy, const void* x,
                                     int64_t ldx, int32_t M, int32_t N, int64_t K, void* workspace,
                                     size_t workspace_bytes, void* stream) {
+  return mmt_wgrad_bias_accumulate(dw, ldw, nullptr, dy, ldy, x, ldx, M, N, K, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, const void* dy, int64_t ldy,
+                                         const void* x, int64_t ldx, int32_t M, int32_t N, int64_t K,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
   if (!dw || !dy || !x) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: NULL argument");
   if (M <= 0 || N <= 0 || K <= 0 || (M % 128) || (N % mmt::kWgTN) || (K % 32))
     return mmt::fail(MMT_E_UNSUPPORTED, "mmt_wgrad_accumulate: needs M %% 128 == 0, N %% 256 == 0, K %% 32 == 0 (got %d, %d, %lld)", M, N, (long long)K);
@@ -222,8 +266,10 @@ extern "C" int mmt_wgrad_accumulate(float* dw, int64_t ldw, const void* dy, int6
   const int kps = (int)(((K + split - 1) / split + 31) / 32 * 32);
   split = (int)((K + kps - 1) / kps);
   p.k_per_split = kps;
-  const size_t need = (size_t)split * M * N * sizeof(float);
+  const size_t need = (size_t)split * ((size_t)M * N + M) * sizeof(float);
   p.slabs = (workspace && workspace_bytes >= need && split > 1) ? (float*)workspace : nullptr;
+  p.dbias = dbias;
+  p.bias_part = (p.slabs && dbias) ? p.slabs + (size_t)split * M * N : nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (tile_m == 256) {
     const int lds = 2 * mmt::WgCfg<4>::kStageBytes;
@@ -236,7 +282,7 @@ extern "C" int mmt_wgrad_accumulate(float* dw, int64_t ldw, const void* dy, int6
   if (e == hipSuccess && p.slabs) {
     long blocks = ((long)M * N / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(mmt::wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw, (long)ldw, p.slabs, split, M, N);
+    hipLaunchKernelGGL(mmt::wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dw, (long)ldw, p.slabs, split, M, N, dbias, p.bias_part);
     e = hipGetLastError();
   }
   return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_wgrad_accumulate: %s", hipGetErrorString(e));

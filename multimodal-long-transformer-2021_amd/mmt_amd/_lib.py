@@ -17,12 +17,14 @@ MMT_ABI_VERSION = 1
 MMT_F32, MMT_BF16 = 0, 1
 MMT_IDS_NONE, MMT_IDS_1D, MMT_IDS_2D = 0, 1, 2
 MMT_FLAG_SCALE_BEFORE_ADD = 1
+MMT_FLAG_ACCUM_REL_GRADS = 2
 
 EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn_fwd',
            'mmt_attn_bwd', 'mmt_side_inputs',
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
-           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_accumulate_grad', 'mmt_adamw_step', 'mmt_wgrad_accumulate', 'mmt_wgrad_workspace_bytes')
+           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_accumulate_grad', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
+           'mmt_wgrad_bias_accumulate', 'mmt_wgrad_workspace_bytes')
 
 
 class RowsDesc(ctypes.Structure):
@@ -118,6 +120,9 @@ def lib() -> ctypes.CDLL:
   L.mmt_wgrad_accumulate.restype = ctypes.c_int
   L.mmt_wgrad_accumulate.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int32,
                                      ctypes.c_int32, ctypes.c_int64, vp, ctypes.c_size_t, vp]
+  L.mmt_wgrad_bias_accumulate.restype = ctypes.c_int
+  L.mmt_wgrad_bias_accumulate.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_int64, vp, ctypes.c_size_t, vp]
   L.mmt_wgrad_workspace_bytes.restype = ctypes.c_size_t
   L.mmt_wgrad_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]
   L.mmt_adamw_step.restype = ctypes.c_int

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 import itertools
 
+from typing import Optional
+
 import torch
 
 from . import _lib
@@ -230,8 +232,9 @@ def accumulate_grad_(acc: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
   return acc
 
 
-def wgrad_accumulate_(dw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor) -> bool:
-  """dw (fp32 [M,N]) += dy[K,M]^T @ x[K,N] (bf16) with the hand-written split-K kernel.
+def wgrad_accumulate_(dw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, dbias: Optional[torch.Tensor] = None) -> bool:
+  """dw (fp32 [M,N]) += dy[K,M]^T @ x[K,N] (bf16) with the hand-written split-K kernel; with
+  `dbias` (fp32 [M], contiguous) also dbias += dy.sum(0) from the same pass over dy.
   Returns False (nothing done) when the shape/layout is outside what the kernel is built for."""
   K, M = dy.shape
   N = x.shape[1]
@@ -239,14 +242,17 @@ def wgrad_accumulate_(dw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor) -> bo
         and dw.shape == (M, N) and x.shape[0] == K and M % 128 == 0 and N % 256 == 0 and K % 32 == 0
         and dw.stride(1) == 1 and dy.stride(1) == 1 and x.stride(1) == 1
         and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
-        and dw.stride(0) % 4 == 0 and dw.data_ptr() % 16 == 0)
+        and dw.stride(0) % 4 == 0 and dw.data_ptr() % 16 == 0
+        and (dbias is None or (dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == M
+                               and dbias.device == dw.device)))
   if not ok:
     return False
   L = _lib.lib()
   ws = _wgrad_ws(dw.device, L.mmt_wgrad_workspace_bytes(M, N, K))
   with torch.cuda.device(dw.device):
-    _lib.check(L.mmt_wgrad_accumulate(dw.data_ptr(), dw.stride(0), dy.data_ptr(), dy.stride(0),
-                                      x.data_ptr(), x.stride(0), M, N, K, ws.data_ptr(), ws.numel(), _stream(dw)))
+    _lib.check(L.mmt_wgrad_bias_accumulate(dw.data_ptr(), dw.stride(0), None if dbias is None else dbias.data_ptr(),
+                                           dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K,
+                                           ws.data_ptr(), ws.numel(), _stream(dw)))
   return True
 
 

@@ -105,19 +105,27 @@ class _LinearFn(torch.autograd.Function):
     if not dy2.is_contiguous():
       dy2 = dy2.contiguous()
     dx = torch.mm(dy2, w).view(x.shape) if ctx.needs_input_grad[0] else None
+    want_b = bias is not None and bias.requires_grad
+    b_done = False
     if weight.requires_grad:
       if weight.grad is None:
         weight.grad = torch.zeros_like(weight, dtype=torch.float32)
-      if not (weight.grad.dtype == torch.float32 and fused.wgrad_accumulate_(weight.grad, dy2, x2)):
-        fused.accumulate_grad_(weight.grad, torch.mm(dy2.t(), x2)) if weight.grad.dtype == torch.float32 \
-            else weight.grad.add_(torch.mm(dy2.t(), x2))
-      _notify(weight)
-    if bias is not None and bias.requires_grad:
-      db = dy2.sum(0, dtype=torch.float32)
-      if bias.grad is None:
-        bias.grad = db.to(bias.dtype)
+      fuse_b = want_b and bias.grad is not None and bias.grad.dtype == torch.float32 and bias.grad.is_contiguous()
+      if weight.grad.dtype == torch.float32 and fused.wgrad_accumulate_(weight.grad, dy2, x2,
+                                                                         bias.grad if fuse_b else None):
+        b_done = fuse_b
+      elif weight.grad.dtype == torch.float32:
+        fused.accumulate_grad_(weight.grad, torch.mm(dy2.t(), x2))
       else:
-        bias.grad.add_(db)
+        weight.grad.add_(torch.mm(dy2.t(), x2))
+      _notify(weight)
+    if want_b:
+      if not b_done:
+        db = dy2.sum(0, dtype=torch.float32)
+        if bias.grad is None:
+          bias.grad = db.to(bias.dtype)
+        else:
+          bias.grad.add_(db)
       _notify(bias)
     return dx, None, None
 
@@ -193,15 +201,24 @@ class RelativeAttention(nn.Module):
               training=False, dropout_seed=0, add_output_bias=True):
     B, S, H = x.shape
     qkv = _linear(x, self.qkv_weight, self.qkv_bias).view(B, S, 3, self.num_heads, self.head_size)
-    emb = None if self.relative_emb_table is None else cast_param(self.relative_emb_table, x.dtype)
-    bias = None if self.relative_bias_table is None else cast_param(self.relative_bias_table, x.dtype)
-    if relative_att_ids is None and (pattern is None or pattern.id_mode == 0):
-      emb = bias = None
+    emb_p, bias_p = self.relative_emb_table, self.relative_bias_table
+    if emb_p is None or (relative_att_ids is None and (pattern is None or pattern.id_mode == 0)):
+      emb = bias = sinks = None
+    elif (x.is_cuda and x.dtype != torch.float32 and torch.is_grad_enabled() and emb_p.requires_grad
+          and emb_p.dtype == torch.float32 and (bias_p is None or (bias_p.requires_grad and bias_p.dtype == torch.float32))):
+      # fp32 masters, low-precision compute: the backward adds the fp32 table gradients into .grad
+      emb = _param_weight(emb_p, x.dtype)
+      bias = None if bias_p is None else _param_weight(bias_p, x.dtype)
+      sinks = (emb_p, bias_p)
+    else:
+      emb = cast_param(emb_p, x.dtype)
+      bias = None if bias_p is None else cast_param(bias_p, x.dtype)
+      sinks = None
     self._calls += 1
     p_drop = self.att_dropout_prob if training else 0.0
     out = ops.relative_attention_qkv(
-        qkv, emb, bias, att_mask=att_mask, relative_att_ids=relative_att_ids, pattern=pattern,
-        valid_len=valid_len, dropout_p=p_drop,
+        qkv, emb, bias, rel_grad_sinks=sinks, att_mask=att_mask, relative_att_ids=relative_att_ids,
+        pattern=pattern, valid_len=valid_len, dropout_p=p_drop,
         dropout_seed=(int(dropout_seed) * 1000003 + self._calls) if p_drop > 0 else 0)
     return _linear(out.reshape(B, S, H), self.output_weight, self.output_bias if add_output_bias else None)
 

@@ -162,12 +162,15 @@ def side_inputs(pattern: AttentionPattern, num_image_wordpieces: torch.Tensor,
 def relative_attention_backward(dout, q, k, v, rel_emb, rel_bias, out, lse, *, att_mask=None,
                                 relative_att_ids=None, pattern: Optional[AttentionPattern] = None,
                                 valid_len=None, scale=None, mask_value=-10000.0,
-                                scale_before_add=False, dropout_p=0.0, dropout_seed=0, grads_out=None):
+                                scale_before_add=False, dropout_p=0.0, dropout_seed=0, grads_out=None,
+                                rel_grads_accum=None):
   """Backward of `relative_attention_forward` (recomputes P from `lse`).
 
   Returns (dq, dk, dv, drel_emb, drel_bias); the table gradients are fp32.  `grads_out` may
   give preallocated (dq, dk, dv) with the strides of (q, k, v) -- e.g. the three slices of one
-  fused [B,S,3,N,D] gradient buffer."""
+  fused [B,S,3,N,D] gradient buffer.  `rel_grads_accum` = (demb [R,N,D], dbias [R,N] | None), fp32
+  and contiguous: the table gradients are ADDED to these buffers (the fp32 master gradients) and
+  returned as such."""
   R = _check_inputs(q, k, v, rel_emb, rel_bias, att_mask, relative_att_ids, valid_len)
   B, S, N, D = q.shape
   dout = dout if dout.stride() == out.stride() else dout.contiguous()
@@ -180,10 +183,20 @@ def relative_attention_backward(dout, q, k, v, rel_emb, rel_bias, out, lse, *, a
   if dq.stride() != q.stride() or dk.stride() != k.stride() or dv.stride() != v.stride():
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-  drel_emb = torch.empty((R, N, D), dtype=torch.float32, device=q.device) if R else None
-  drel_bias = torch.empty((R, N), dtype=torch.float32, device=q.device) if (R and rel_bias is not None) else None
   desc = _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_before_add,
                     dropout_p, dropout_seed)
+  if rel_grads_accum is not None and R:
+    drel_emb, drel_bias = rel_grads_accum
+    for t, shape in ((drel_emb, (R, N, D)), (drel_bias, (R, N))):
+      if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous()
+                            or t.device != q.device):
+        raise ValueError(f'rel_grads_accum buffers must be contiguous fp32 {shape} on {q.device}')
+    if rel_bias is not None and drel_bias is None:
+      raise ValueError('rel_grads_accum needs a dbias buffer when rel_bias is given')
+    desc.flags |= _lib.MMT_FLAG_ACCUM_REL_GRADS
+  else:
+    drel_emb = torch.empty((R, N, D), dtype=torch.float32, device=q.device) if R else None
+    drel_bias = torch.empty((R, N), dtype=torch.float32, device=q.device) if (R and rel_bias is not None) else None
   L = _lib.lib()
   ws_bytes = L.mmt_workspace_bytes(desc)
   ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=q.device)
@@ -228,11 +241,11 @@ class _RelativeAttentionQkvFn(torch.autograd.Function):
   into the three slices of ONE gradient buffer (no per-slice zero-fill / copy in autograd)."""
 
   @staticmethod
-  def forward(ctx, qkv, rel_emb, rel_bias, kw):
+  def forward(ctx, qkv, rel_emb, rel_bias, kw, sinks):
     q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
     out, lse = relative_attention_forward(q, k, v, rel_emb, rel_bias, **kw)
     ctx.save_for_backward(qkv, rel_emb, rel_bias, out, lse)
-    ctx.kw = kw
+    ctx.kw, ctx.sinks = kw, sinks
     return out
 
   @staticmethod
@@ -240,17 +253,37 @@ class _RelativeAttentionQkvFn(torch.autograd.Function):
     qkv, rel_emb, rel_bias, out, lse = ctx.saved_tensors
     kw = {a: b for a, b in ctx.kw.items() if a != 'return_lse'}
     dqkv = torch.empty_like(qkv)
+    accum = None
+    if ctx.sinks is not None and rel_emb is not None:     # fp32 master tables: add straight into .grad
+      for p in ctx.sinks:
+        if p is not None and p.grad is None:
+          p.grad = torch.zeros_like(p, dtype=torch.float32)
+      accum = (ctx.sinks[0].grad, None if ctx.sinks[1] is None else ctx.sinks[1].grad)
     _, _, _, de, db = relative_attention_backward(
         dout, qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], rel_emb, rel_bias, out, lse,
-        grads_out=(dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]), **kw)
+        grads_out=(dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]), rel_grads_accum=accum, **kw)
+    if accum is not None:
+      for p in ctx.sinks:
+        for hook in getattr(p, '_mmt_grad_ready_hooks', ()) if p is not None else ():
+          hook(p)
+      return dqkv, None, None, None, None
     de = None if de is None else de.to(rel_emb.dtype)
     db = None if db is None else db.to(rel_bias.dtype)
-    return dqkv, de, db, None
+    return dqkv, de, db, None, None
 
 
-def relative_attention_qkv(qkv, rel_emb=None, rel_bias=None, **kw):
-  """`relative_attention` on a fused, contiguous qkv [B,S,3,N,D] tensor."""
+def relative_attention_qkv(qkv, rel_emb=None, rel_bias=None, rel_grad_sinks=None, **kw):
+  """`relative_attention` on a fused, contiguous qkv [B,S,3,N,D] tensor.
+
+  `rel_grad_sinks` = (emb_master, bias_master | None): fp32 master parameters whose low-precision
+  copies are `rel_emb` / `rel_bias` (passed detached).  The backward then adds the fp32 table
+  gradients straight into their `.grad` (no bf16 round trip, no separate accumulate kernels) and
+  runs their `_mmt_grad_ready_hooks`."""
   if qkv.dim() != 5 or qkv.shape[2] != 3 or not qkv.is_contiguous():
     raise ValueError('qkv must be a contiguous [B,S,3,N,D] tensor')
   kw.pop('return_lse', None)
-  return _RelativeAttentionQkvFn.apply(qkv, rel_emb, rel_bias, kw)
+  if rel_grad_sinks is not None:
+    for p in rel_grad_sinks:
+      if p is not None and (p.dtype != torch.float32 or not p.is_contiguous()):
+        raise ValueError('rel_grad_sinks must be contiguous fp32 parameters')
+  return _RelativeAttentionQkvFn.apply(qkv, rel_emb, rel_bias, kw, rel_grad_sinks)

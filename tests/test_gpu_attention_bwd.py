@@ -90,3 +90,51 @@ def test_dense_operator_backward(cfg, dtype):
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'id_mode')))
 def test_structured_pattern_backward(cfg, dtype):
   run_bwd(dtype=dtype, dense=False, **cfg)
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_rel_grads_accumulate_into_master_buffers(dtype):
+  """MMT_FLAG_ACCUM_REL_GRADS: drel_emb / drel_bias are added to caller buffers (fp32 master
+  gradients) -- bit-identical to the overwrite mode's result plus the buffer's old contents."""
+  import mmt_amd
+  B, S, N, R = 2, 160, 2, 9
+  q, k, v, emb, bias = (torch.from_numpy(x).cuda().to(dtype) for x in attention_inputs(B, S, N, R, 5))
+  pat = mmt_amd.AttentionPattern(local_radius=24, global_start=150, n_global=4, id_mode=1, max_dist=4)
+  out, lse = mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat)
+  dout = torch.randn_like(out)
+  dq, dk, dv, de, db = mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, out, lse, pattern=pat)
+  de0, db0 = torch.randn_like(de), torch.randn_like(db)
+  de1, db1 = de0.clone(), db0.clone()
+  dq2, dk2, dv2, de2, db2 = mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, out, lse, pattern=pat,
+                                                                rel_grads_accum=(de1, db1))
+  assert de2 is de1 and db2 is db1
+  assert torch.equal(de1, de0 + de) and torch.equal(db1, db0 + db)
+  assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv)
+  with pytest.raises(ValueError):
+    mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, out, lse, pattern=pat,
+                                        rel_grads_accum=(de1.to(torch.bfloat16), db1))
+
+
+def test_qkv_fn_adds_fp32_table_gradients_to_master_params():
+  """relative_attention_qkv(rel_grad_sinks=...): the fp32 table gradients land in the master
+  parameters' .grad (accumulating over calls) and match the autograd path's bf16-rounded ones."""
+  import mmt_amd
+  torch.manual_seed(3)
+  B, S, N, R = 1, 192, 2, 9
+  qkv = torch.randn(B, S, 3, N, 64, device='cuda', dtype=torch.bfloat16, requires_grad=True)
+  emb_p = torch.nn.Parameter(torch.randn(R, N, 64, device='cuda') * 0.1)
+  bias_p = torch.nn.Parameter(torch.randn(R, N, device='cuda') * 0.1)
+  pat = mmt_amd.AttentionPattern(local_radius=32, global_start=180, n_global=4, id_mode=1, max_dist=4)
+  g = torch.randn(B, S, N, 64, device='cuda', dtype=torch.bfloat16)
+  fired = []
+  emb_p._mmt_grad_ready_hooks = [lambda p: fired.append('emb')]
+  for _ in range(2):      # two micro-steps accumulate
+    mmt_amd.relative_attention_qkv(qkv, emb_p.detach().bfloat16(), bias_p.detach().bfloat16(),
+                                   rel_grad_sinks=(emb_p, bias_p), pattern=pat).backward(g)
+  assert fired == ['emb', 'emb'] and emb_p.grad.dtype == torch.float32
+  e2 = emb_p.detach().bfloat16().requires_grad_(True)
+  b2 = bias_p.detach().bfloat16().requires_grad_(True)
+  mmt_amd.relative_attention_qkv(qkv, e2, b2, pattern=pat).backward(g)
+  for got, want in ((emb_p.grad, e2.grad), (bias_p.grad, b2.grad)):
+    err = float((got / 2 - want.float()).abs().max()) / float(want.float().abs().max())
+    assert err < 1e-2, err

@@ -169,15 +169,23 @@ def test_wgrad_accumulate(K, M, N, use_ws):
   dy = torch.randn(K, M, device='cuda').to(torch.bfloat16)
   x = torch.randn(K, N, device='cuda').to(torch.bfloat16)
   dw0 = torch.randn(M, N, device='cuda')
-  dw = dw0.clone()
+  db0 = torch.randn(M, device='cuda')
+  dw, db = dw0.clone(), db0.clone()
   if use_ws:
-    assert fused.wgrad_accumulate_(dw, dy, x)
+    assert fused.wgrad_accumulate_(dw, dy, x, db)
   else:   # no workspace: float-atomic epilogue
-    _lib.check(_lib.lib().mmt_wgrad_accumulate(dw.data_ptr(), N, dy.data_ptr(), M, x.data_ptr(), N, M, N, K, None, 0,
-                                               torch.cuda.current_stream().cuda_stream))
+    _lib.check(_lib.lib().mmt_wgrad_bias_accumulate(dw.data_ptr(), N, db.data_ptr(), dy.data_ptr(), M, x.data_ptr(), N,
+                                                    M, N, K, None, 0, torch.cuda.current_stream().cuda_stream))
   want = dw0.double() + dy.double().t() @ x.double()
   err = float((dw.double() - want).abs().max()) / float(want.abs().max())
   assert err < 2e-5, err
+  want_b = db0.double() + dy.double().sum(0)            # bias gradient from the same pass over dy
+  err_b = float((db.double() - want_b).abs().max()) / float(want_b.abs().max())
+  assert err_b < 2e-5, err_b
+  dw2 = dw0.clone()                                     # without dbias: the plain entry point, same dW
+  assert fused.wgrad_accumulate_(dw2, dy, x)
+  if use_ws:
+    assert torch.equal(dw2, dw)                         # slab mode is bitwise reproducible
   assert not fused.wgrad_accumulate_(dw, dy[:, :100].contiguous(), x)       # unsupported shape -> caller falls back
 
 

@@ -21,3 +21,7 @@ def t(fn, n=20):
   return e0.elapsed_time(e1) / n * 1e3
 print('fwd us', round(t(lambda: mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat)), 1))
 print('bwd us', round(t(lambda: mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, out, lse, pattern=pat)), 1))
+kw = dict(pattern=pat, dropout_p=0.1, dropout_seed=1234)
+out, lse = mmt_amd.relative_attention_forward(q, k, v, emb, bias, **kw)
+print('fwd+dropout us', round(t(lambda: mmt_amd.relative_attention_forward(q, k, v, emb, bias, **kw)), 1))
+print('bwd+dropout us', round(t(lambda: mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, out, lse, **kw)), 1))

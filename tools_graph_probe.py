@@ -1,0 +1,26 @@
+"""Dev tool: replay one train step as a hipGraph to see the GPU-bound step time (not the product path:
+the capture bakes lr / seeds of one step)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'multimodal-long-transformer-2021_amd'))
+import torch
+from mmt_amd import benchmarks
+import bench
+step, info = benchmarks.make_train_step_bench(bench.config3(), torch.device('cuda:0'), 0, 1)
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+  for _ in range(5): step()
+torch.cuda.current_stream().wait_stream(s)
+torch.cuda.synchronize()
+def timeit(fn, n=20):
+  torch.cuda.synchronize(); t0 = time.perf_counter()
+  for _ in range(n): fn()
+  torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+print('eager ms/step', round(timeit(step), 3))
+g = torch.cuda.CUDAGraph()
+try:
+  with torch.cuda.graph(g):
+    step()
+  print('graph ms/step', round(timeit(g.replay), 3))
+except Exception as e:
+  print('capture failed:', repr(e)[:2000])
