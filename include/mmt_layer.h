@@ -100,7 +100,7 @@ int mmt_adamw_step(const mmt_adamw_desc* desc, float* param, float* grad, float*
 /* Weight gradient of a Dense layer, accumulated into the fp32 master gradient:
  *   dw[M,N] += dy[K,M]^T . x[K,N]        (bf16 operands, fp32 accumulation, float atomics)
  * = the per-layer `tape.gradient` product + `AccumulateGrad` of src/tasks/pretraining.py:262-296.
- * Requires M % 128 == 0, N % 256 == 0, K % 32 == 0, 16-byte aligned operands, ld* in elements
+ * Requires M % 128 == 0, N % 256 == 0 (any K), 16-byte aligned operands, ld* in elements
  * (ldy, ldx multiples of 8); returns MMT_E_UNSUPPORTED otherwise (callers fall back to a
  * library GEMM).  With a workspace of mmt_wgrad_workspace_bytes() the split-K partials are
  * written as plain fp32 slabs and summed in fixed order (bitwise reproducible); without one they
@@ -115,6 +115,53 @@ int mmt_wgrad_accumulate(float* dw, int64_t ldw, const void* dy, int64_t ldy, co
 int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, const void* dy, int64_t ldy,
                               const void* x, int64_t ldx, int32_t M, int32_t N, int64_t K,
                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding assembly of MmtEncoder.call (src/modeling/models/mmt_encoder.py:189-218):
+ *   we  = Dropout(LayerNorm_eps(WordEmb[word_ids]))          LN + dropout on the WORD embeddings only
+ *   out = we + SegEmb[segment_ids] (+ PosEmb[s]) (+ patch_proj[b, s - patch_start] + patch_bias
+ *                                                 for patch_start <= s < patch_start + n_patch)
+ * in one pass per row (one wave per row; tables fp32, `out` in `dtype`).  What TF runs as gather /
+ * one-hot matmul, LayerNormalization, Dropout, three Adds, a Pad and a Cast.
+ * Ids outside [0, vocab) contribute a zero row (one-hot lookup semantics, mmt_encoder.py:110).
+ * patch_proj is the [B, n_patch, H] output of the patch projection GEMM WITHOUT its bias, in `dtype`. */
+typedef struct mmt_embed_desc {
+  int64_t rows;          /* B * S                                                        */
+  int32_t S;             /* sequence length: row = b * S + s                             */
+  int32_t H;             /* hidden size = embedding size; multiple of 8, <= 2048         */
+  int32_t dtype;         /* MMT_F32 | MMT_BF16: out / patch_proj / dout / dpatch         */
+  int32_t vocab;         /* rows of word_table                                           */
+  int32_t seg_vocab;     /* rows of seg_table                                            */
+  int32_t patch_start;   /* 2 in the reference ([CLS], [PATCH] first; mmt_encoder.py:213-218) */
+  int32_t n_patch;       /* 0: no patch term                                             */
+  float eps;             /* 1e-12                                                        */
+  float dropout_p;       /* hidden_dropout_prob; 0 disables                              */
+  int32_t accumulate;    /* backward: != 0 adds dgamma / dbeta INTO the given buffers     */
+  uint64_t dropout_seed;
+} mmt_embed_desc;
+
+int mmt_embed_fwd(const mmt_embed_desc* desc, const int32_t* word_ids, const int32_t* seg_ids,
+                  const float* word_table, const float* seg_table, const float* pos_table /* nullable */,
+                  const float* gamma, const float* beta, const void* patch_proj /* nullable */,
+                  const float* patch_bias /* nullable */, void* out, float* mean, float* rstd,
+                  void* stream);
+
+/* Bytes of scratch mmt_embed_bwd needs. */
+size_t mmt_embed_workspace_bytes(const mmt_embed_desc* desc);
+
+/* Backward of mmt_embed_fwd for the word path and the patch slice:
+ *   dword_table[id] += LayerNormBwd(DropoutBwd(dout[row]))   summed over the rows holding id,
+ *   dgamma / dbeta (overwritten, or added to with desc->accumulate),
+ *   dpatch[b, j] = dout[b, patch_start + j]                   (compact copy for the projection's wgrad GEMM; nullable).
+ * `order` = the permutation that sorts word_ids ascending (stable: ties in row order) -- rows with
+ * the same id are then adjacent and are summed in that fixed order by ONE wave per id (runs longer
+ * than 32 go through per-32 partial sums), so the scatter needs no atomics and is bitwise reproducible.
+ * dword_table is fp32 [vocab, H] and is ACCUMULATED into (the master gradient).  The segment /
+ * position table gradients are plain column sums of dout and are left to the caller. */
+int mmt_embed_bwd(const mmt_embed_desc* desc, const void* dout, const int32_t* word_ids,
+                  const int32_t* order, const float* word_table, const float* gamma, const float* mean,
+                  const float* rstd, float* dword_table, float* dgamma, float* dbeta, void* dpatch,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

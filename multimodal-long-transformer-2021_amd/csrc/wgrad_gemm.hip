@@ -56,25 +56,27 @@ __global__ __launch_bounds__(128 * MW, 2) void wgrad_kernel(const WgradParams p)
   const int m0 = tm * kWgTM, n0 = tn * kWgTN;
   const int k_begin = ks * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
-  const int n_steps = (k_end - k_begin) >> 5;
+  const int n_steps = (k_end - k_begin + 31) >> 5;      // the last step may be ragged: rows >= K stage as zeros
   if (n_steps <= 0) return;
 
   // ---- staging map: 16-byte chunks; A slab 32 x 128 cols = 512 chunks (2 per thread),
   //      B slab 32 x 256 cols = 1024 chunks (4 per thread) -------------------------------------
   constexpr int kAChunksRow = kWgTM / 8;      // 16-byte chunks per A-slab row
-  const __bf16* ga[2]; int la[2];
-  const __bf16* gb[C::kBPer]; int lb[C::kBPer];
+  const __bf16* ga[2]; int la[2], ka[2];
+  const __bf16* gb[C::kBPer]; int lb[C::kBPer], kb[C::kBPer];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int c = tid + C::kThreads * u, row = c / kAChunksRow, ch = c % kAChunksRow;
     ga[u] = p.dy + (long)(k_begin + row) * p.ldy + m0 + ch * 8;
     la[u] = (ch >> 3) * 4096 + vtile_off(row, ch & 7);
+    ka[u] = k_begin + row;
   }
 #pragma unroll
   for (int u = 0; u < C::kBPer; ++u) {
     const int c = tid + C::kThreads * u, row = c >> 5, ch = c & 31;
     gb[u] = p.x + (long)(k_begin + row) * p.ldx + n0 + ch * 8;
     lb[u] = kWgTM * 64 + (ch >> 3) * 4096 + vtile_off(row, ch & 7);
+    kb[u] = k_begin + row;
   }
   const long astep = 32 * p.ldy, bstep = 32 * p.ldx;
 
@@ -105,9 +107,9 @@ __global__ __launch_bounds__(128 * MW, 2) void wgrad_kernel(const WgradParams p)
 
   bf16x8 ra[2], rb[C::kBPer];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const bf16x8*>(ga[u]);
+  for (int u = 0; u < 2; ++u) ra[u] = ka[u] < k_end ? *reinterpret_cast<const bf16x8*>(ga[u]) : bf16x8{0};
 #pragma unroll
-  for (int u = 0; u < C::kBPer; ++u) rb[u] = *reinterpret_cast<const bf16x8*>(gb[u]);
+  for (int u = 0; u < C::kBPer; ++u) rb[u] = kb[u] < k_end ? *reinterpret_cast<const bf16x8*>(gb[u]) : bf16x8{0};
 #pragma unroll
   for (int u = 0; u < 2; ++u) *reinterpret_cast<bf16x8*>(smem + la[u]) = ra[u];
 #pragma unroll
@@ -120,10 +122,11 @@ __global__ __launch_bounds__(128 * MW, 2) void wgrad_kernel(const WgradParams p)
     unsigned char* nxt = smem + ((step + 1) & 1) * kWgStageBytes;
     const bool more = step + 1 < n_steps;
     if (more) {          // next slab: global -> registers, in flight under this step's MFMAs
+      const int kleft = k_end - 32 * (step + 1);
 #pragma unroll
-      for (int u = 0; u < 2; ++u) ra[u] = *reinterpret_cast<const bf16x8*>(ga[u] + (long)(step + 1) * astep);
+      for (int u = 0; u < 2; ++u) ra[u] = ka[u] < kleft ? *reinterpret_cast<const bf16x8*>(ga[u] + (long)(step + 1) * astep) : bf16x8{0};
 #pragma unroll
-      for (int u = 0; u < C::kBPer; ++u) rb[u] = *reinterpret_cast<const bf16x8*>(gb[u] + (long)(step + 1) * bstep);
+      for (int u = 0; u < C::kBPer; ++u) rb[u] = kb[u] < kleft ? *reinterpret_cast<const bf16x8*>(gb[u] + (long)(step + 1) * bstep) : bf16x8{0};
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -251,8 +254,8 @@ extern "C" int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, c
                                          const void* x, int64_t ldx, int32_t M, int32_t N, int64_t K,
                                          void* workspace, size_t workspace_bytes, void* stream) {
   if (!dw || !dy || !x) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: NULL argument");
-  if (M <= 0 || N <= 0 || K <= 0 || (M % 128) || (N % mmt::kWgTN) || (K % 32))
-    return mmt::fail(MMT_E_UNSUPPORTED, "mmt_wgrad_accumulate: needs M %% 128 == 0, N %% 256 == 0, K %% 32 == 0 (got %d, %d, %lld)", M, N, (long long)K);
+  if (M <= 0 || N <= 0 || K <= 0 || (M % 128) || (N % mmt::kWgTN))
+    return mmt::fail(MMT_E_UNSUPPORTED, "mmt_wgrad_accumulate: needs M %% 128 == 0, N %% 256 == 0 (got %d, %d, K = %lld)", M, N, (long long)K);
   if ((ldy % 8) || (ldx % 8) || ldy < M || ldx < N || ldw < N || (ldw % 4)) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: bad leading dimensions");
   if (((uintptr_t)dy & 15) || ((uintptr_t)x & 15) || ((uintptr_t)dw & 15)) return mmt::fail(MMT_E_INVALID, "mmt_wgrad_accumulate: operands must be 16-byte aligned");
   mmt::WgradParams p;

@@ -24,7 +24,15 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
            'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_accumulate_grad', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
-           'mmt_wgrad_bias_accumulate', 'mmt_wgrad_workspace_bytes')
+           'mmt_wgrad_bias_accumulate', 'mmt_wgrad_workspace_bytes', 'mmt_embed_fwd', 'mmt_embed_bwd',
+           'mmt_embed_workspace_bytes')
+
+
+class EmbedDesc(ctypes.Structure):
+  _fields_ = [('rows', ctypes.c_int64), ('S', ctypes.c_int32), ('H', ctypes.c_int32), ('dtype', ctypes.c_int32),
+              ('vocab', ctypes.c_int32), ('seg_vocab', ctypes.c_int32), ('patch_start', ctypes.c_int32),
+              ('n_patch', ctypes.c_int32), ('eps', ctypes.c_float), ('dropout_p', ctypes.c_float),
+              ('accumulate', ctypes.c_int32), ('dropout_seed', ctypes.c_uint64)]
 
 
 class RowsDesc(ctypes.Structure):
@@ -123,6 +131,13 @@ def lib() -> ctypes.CDLL:
   L.mmt_wgrad_bias_accumulate.restype = ctypes.c_int
   L.mmt_wgrad_bias_accumulate.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int64, vp, ctypes.c_size_t, vp]
+  ed = ctypes.POINTER(EmbedDesc)
+  L.mmt_embed_fwd.restype = ctypes.c_int
+  L.mmt_embed_fwd.argtypes = [ed] + [vp] * 13
+  L.mmt_embed_bwd.restype = ctypes.c_int
+  L.mmt_embed_bwd.argtypes = [ed] + [vp] * 12 + [ctypes.c_size_t, vp]
+  L.mmt_embed_workspace_bytes.restype = ctypes.c_size_t
+  L.mmt_embed_workspace_bytes.argtypes = [ed]
   L.mmt_wgrad_workspace_bytes.restype = ctypes.c_size_t
   L.mmt_wgrad_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]
   L.mmt_adamw_step.restype = ctypes.c_int

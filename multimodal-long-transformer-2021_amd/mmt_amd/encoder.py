@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import layers
+from . import fused, layers
 from .ops import AttentionPattern
 
 _NUM_OTHER_RELATIVE_IDS = 3   # mmt_encoder.py:25
@@ -92,15 +92,38 @@ class MmtEncoder(nn.Module):
     }
     self._config = collections.namedtuple('Config', config_dict.keys())(**config_dict)
     self._step = 0
+    self.use_fused_embedding = True
+
+  def _fused_embed_ok(self, word_ids):
+    w, sg = self._word_embedding_layer, self._segment_embedding_layer
+    H = w.embedding_table.shape[1]
+    return (word_ids.is_cuda and w.embedding_projection is None and sg.embedding_projection is None
+            and self.compute_dtype in (torch.float32, torch.bfloat16) and H % 8 == 0 and H <= 2048
+            and w.embedding_table.dtype == torch.float32 and sg.embedding_table.dtype == torch.float32
+            and sg.embedding_table.shape[1] == H and self.use_fused_embedding)
 
   def embed(self, word_ids, segment_ids=None, patch_embeddings=None, training=False):
     """Embedding assembly, `mmt_encoder.py:189-218`: LayerNorm + dropout on
-    the WORD embeddings only; segment / position / projected patches are added afterwards."""
+    the WORD embeddings only; segment / position / projected patches are added afterwards.
+    On the GPU this is one HIP kernel (`fused.embed_assemble`) writing the compute dtype; the
+    patch projection runs in the compute dtype like every other Dense layer of the stack."""
     if segment_ids is None:
       segment_ids = torch.ones_like(word_ids)
+    ln = self._embedding_norm_layer
+    if self._fused_embed_ok(word_ids):
+      cd = self.compute_dtype
+      pe = None
+      if patch_embeddings is not None:
+        pe = layers._linear(patch_embeddings.to(cd), self._patch_projection_weight, self._patch_projection_bias)
+        if word_ids.shape[1] < 2 + pe.shape[1]:
+          raise ValueError('sequence too short for [CLS], [PATCH] and the patches')
+      p = self._hidden_dropout_prob if training else 0.0
+      return fused.embed_assemble(word_ids, segment_ids, self._word_embedding_layer.embedding_table,
+                                  self._segment_embedding_layer.embedding_table, ln.weight, ln.bias,
+                                  pos_table=self._position_embeddings, patch_proj=pe, eps=ln.eps, p=p,
+                                  seed=fused.next_seed(self._step) if p else 0, patch_start=2, out_dtype=cd)
     word = self._word_embedding_layer(word_ids)
     seg = self._segment_embedding_layer(segment_ids)
-    ln = self._embedding_norm_layer
     word = F.layer_norm(word, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
     word = F.dropout(word, self._hidden_dropout_prob, training)
     emb = word + seg

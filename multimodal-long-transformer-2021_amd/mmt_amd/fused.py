@@ -239,7 +239,7 @@ def wgrad_accumulate_(dw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, dbias
   K, M = dy.shape
   N = x.shape[1]
   ok = (dw.is_cuda and dw.dtype == torch.float32 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
-        and dw.shape == (M, N) and x.shape[0] == K and M % 128 == 0 and N % 256 == 0 and K % 32 == 0
+        and dw.shape == (M, N) and x.shape[0] == K and M % 128 == 0 and N % 256 == 0 and K > 0
         and dw.stride(1) == 1 and dy.stride(1) == 1 and x.stride(1) == 1
         and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
         and dw.stride(0) % 4 == 0 and dw.data_ptr() % 16 == 0
@@ -266,3 +266,116 @@ def _wgrad_ws(device, nbytes):
     buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=device)
     _WGRAD_WS[device] = buf
   return buf
+
+
+# ---- embedding assembly (MmtEncoder.call, mmt_encoder.py:189-218) --------------------------------
+def _dtype_code(dt):
+  if dt == torch.float32:
+    return _lib.MMT_F32
+  if dt == torch.bfloat16:
+    return _lib.MMT_BF16
+  raise TypeError(f'embed_assemble supports float32 and bfloat16 outputs, got {dt}')
+
+
+def _mm_f32(a, b):
+  """a @ b with fp32 output for low-precision operands (fp32 accumulation either way)."""
+  if a.dtype == torch.float32:
+    return torch.mm(a, b)
+  try:
+    return torch.mm(a, b, out_dtype=torch.float32)
+  except (TypeError, RuntimeError):
+    return torch.mm(a.float(), b.float())
+
+
+class _EmbedAssembleFn(torch.autograd.Function):
+  """Dropout(LN(WordEmb[ids])) + SegEmb[seg] (+ PosEmb) (+ projected patches) in one kernel.
+
+  Backward: the word-table gradient (a scatter-add) is added straight into `word_table.grad`
+  (fp32, created if missing) by `mmt_embed_bwd` and `None` is returned for it -- the table's own
+  AccumulateGrad (tied MaskedLM logits) still runs after this node, so gradient-ready hooks fire
+  once; dgamma / dbeta go straight into existing fp32 `.grad`s when possible."""
+
+  @staticmethod
+  def forward(ctx, word_ids, seg_ids, word_table, seg_table, pos_table, gamma, beta, patch_proj, cfg):
+    eps, p, seed, patch_start, out_dtype = cfg
+    _check(word_ids, seg_ids, word_table, seg_table, gamma, beta, patch_proj, pos_table)
+    B, S = word_ids.shape
+    V, H = word_table.shape
+    ids = word_ids.reshape(-1).to(torch.int32).contiguous()
+    seg = seg_ids.reshape(-1).to(torch.int32).contiguous()
+    wt, st = _f32(word_table.detach()), _f32(seg_table.detach())
+    pt = None if pos_table is None else _f32(pos_table.detach())
+    if pt is not None and pt.shape[0] < S:
+      raise ValueError(f'position table has {pt.shape[0]} rows, sequence length is {S}')
+    g32, b32 = _f32(gamma.detach()), _f32(beta.detach())
+    n_patch = 0
+    if patch_proj is not None:
+      if patch_proj.dim() != 3 or patch_proj.shape[0] != B or patch_proj.shape[2] != H or patch_proj.dtype != out_dtype:
+        raise ValueError('patch_proj must be [B, n_patch, H] in the output dtype')
+      patch_proj = patch_proj.contiguous()
+      n_patch = patch_proj.shape[1]
+    d = _lib.EmbedDesc()
+    d.rows, d.S, d.H, d.dtype = B * S, S, H, _dtype_code(out_dtype)
+    d.vocab, d.seg_vocab, d.patch_start, d.n_patch = V, st.shape[0], int(patch_start), n_patch
+    d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), int(seed) & ((1 << 64) - 1)
+    out = torch.empty((B, S, H), dtype=out_dtype, device=word_table.device)
+    mean = torch.empty(B * S, dtype=torch.float32, device=out.device)
+    rstd = torch.empty_like(mean)
+    with torch.cuda.device(out.device):
+      _lib.check(_lib.lib().mmt_embed_fwd(d, _p(ids), _p(seg), _p(wt), _p(st), _p(pt), _p(g32), _p(b32),
+                                          _p(patch_proj), None, _p(out), _p(mean), _p(rstd), _stream(out)))
+    ctx.save_for_backward(ids, seg, wt, g32, mean, rstd)
+    ctx.desc, ctx.params = d, (word_table, seg_table, pos_table, gamma, beta)
+    ctx.has_patch = patch_proj is not None
+    return out
+
+  @staticmethod
+  def backward(ctx, dout):
+    ids, seg, wt, g32, mean, rstd = ctx.saved_tensors
+    word_table, seg_table, pos_table, gamma, beta = ctx.params
+    d = ctx.desc
+    B, S, H = dout.shape
+    dout2 = dout.reshape(B * S, H).contiguous()
+    order = torch.sort(ids, stable=True).indices.to(torch.int32)     # equal ids adjacent, ties in row order
+    if isinstance(word_table, torch.nn.Parameter) and word_table.requires_grad:
+      if word_table.grad is None:
+        word_table.grad = torch.zeros_like(word_table, dtype=torch.float32)
+      dword = word_table.grad
+      if dword.dtype != torch.float32 or not dword.is_contiguous():
+        raise RuntimeError('embed_assemble: word_table.grad must be a contiguous fp32 tensor')
+    else:
+      dword = torch.zeros(wt.shape, dtype=torch.float32, device=wt.device)
+    (dg, dg_direct), (db, db_direct) = _grad_target(gamma, g32), _grad_target(beta, g32)
+    direct = dg_direct and db_direct
+    if not direct:
+      dg, db = torch.empty_like(g32), torch.empty_like(g32)
+    d.accumulate = int(direct)
+    need_patch = ctx.has_patch and ctx.needs_input_grad[7]
+    dpatch = torch.empty((B, d.n_patch, H), dtype=dout.dtype, device=dout.device) if need_patch else None
+    L = _lib.lib()
+    n = L.mmt_embed_workspace_bytes(d)
+    ws = torch.empty((max(n, 16),), dtype=torch.uint8, device=dout.device)
+    with torch.cuda.device(dout.device):
+      _lib.check(L.mmt_embed_bwd(d, _p(dout2), _p(ids), _p(order), _p(wt), _p(g32), _p(mean), _p(rstd), _p(dword),
+                                 _p(dg), _p(db), _p(dpatch), _p(ws), ws.numel(), _stream(dout)))
+    dword_ret = None
+    if dword is not getattr(word_table, 'grad', None) and ctx.needs_input_grad[2]:
+      dword_ret = dword.to(word_table.dtype)
+    dseg = dpos = None
+    if ctx.needs_input_grad[3]:     # segment table: one-hot^T @ dout (the reference's one-hot lookup, transposed)
+      onehot = torch.nn.functional.one_hot(seg.long().clamp_(0, seg_table.shape[0] - 1), seg_table.shape[0])
+      onehot = (onehot * ((seg >= 0) & (seg < seg_table.shape[0])).unsqueeze(1)).to(dout2.dtype)
+      dseg = _mm_f32(onehot.t(), dout2).to(seg_table.dtype)
+    if pos_table is not None and ctx.needs_input_grad[4]:
+      dpos = torch.zeros(pos_table.shape, dtype=torch.float32, device=dout.device)
+      dpos[:S] = dout.sum(0, dtype=torch.float32)
+      dpos = dpos.to(pos_table.dtype)
+    return (None, None, dword_ret, dseg, dpos, _finish(gamma, dg, direct), _finish(beta, db, direct), dpatch, None)
+
+
+def embed_assemble(word_ids, seg_ids, word_table, seg_table, gamma, beta, pos_table=None, patch_proj=None,
+                   eps=1e-12, p=0.0, seed=0, patch_start=2, out_dtype=torch.bfloat16):
+  """[B,S] ids -> [B,S,H] embeddings in `out_dtype` (see `_EmbedAssembleFn`); `patch_proj`
+  [B, n_patch, H] (projection bias included) is added at positions [patch_start, patch_start+n_patch)."""
+  return _EmbedAssembleFn.apply(word_ids, seg_ids, word_table, seg_table, pos_table, gamma, beta, patch_proj,
+                                (eps, p, seed, patch_start, out_dtype))

@@ -80,3 +80,52 @@ def gelu_tanh_grad(z):
   k = np.sqrt(2.0 / np.pi)
   t = np.tanh(k * (z + 0.044715 * z ** 3))
   return 0.5 * (1 + t) + 0.5 * z * (1 - t * t) * k * (1 + 3 * 0.044715 * z * z)
+
+
+# ---- embedding assembly (src/modeling/models/mmt_encoder.py:189-218) ----------
+def embed_assemble_fwd(word_ids, seg_ids, word_table, seg_table, gamma, beta, pos_table=None,
+                       patch_proj=None, patch_start=2, keep=None, inv_keep=1.0, eps=1e-12):
+  """out[b,s] = Dropout(LN(WordEmb[word_ids])) + SegEmb[seg_ids] (+ PosEmb[s]) (+ patches at
+  [patch_start, patch_start + n_patch)).  Ids outside the table contribute a zero row (one-hot
+  lookup, mmt_encoder.py:110).  `patch_proj` [B, n_patch, H] already includes the projection bias.
+  `keep` [B*S, H] is the explicit dropout mask on the LayerNorm output."""
+  B, S = word_ids.shape
+  V, H = word_table.shape
+  ok = (word_ids >= 0) & (word_ids < V)
+  we = np.where(ok[..., None], word_table[np.clip(word_ids, 0, V - 1)], 0.0)
+  we, mu, rstd = layer_norm(we, gamma, beta, eps)
+  if keep is not None:
+    we = np.where(keep.reshape(B, S, H), we * inv_keep, 0.0)
+  sok = (seg_ids >= 0) & (seg_ids < seg_table.shape[0])
+  out = we + np.where(sok[..., None], seg_table[np.clip(seg_ids, 0, seg_table.shape[0] - 1)], 0.0)
+  if pos_table is not None:
+    out = out + pos_table[:S][None]
+  if patch_proj is not None:
+    n = patch_proj.shape[1]
+    out[:, patch_start:patch_start + n] += patch_proj
+  return out
+
+
+def embed_assemble_bwd(dout, word_ids, seg_ids, word_table, seg_table, gamma, n_patch=0, patch_start=2,
+                       keep=None, inv_keep=1.0, eps=1e-12, has_pos=False):
+  """Gradients of embed_assemble_fwd: dict(word_table, seg_table, gamma, beta, patch_proj, pos)."""
+  B, S = word_ids.shape
+  V, H = word_table.shape
+  d = dout.reshape(B * S, H)
+  ids = word_ids.reshape(-1)
+  ok = (ids >= 0) & (ids < V)
+  x = np.where(ok[:, None], word_table[np.clip(ids, 0, V - 1)], 0.0)
+  t = d if keep is None else np.where(keep, d * inv_keep, 0.0)
+  dx, dgamma, dbeta = layer_norm_bwd(t, x, gamma, eps)
+  dword = np.zeros_like(word_table)
+  np.add.at(dword, ids[ok], dx[ok])
+  dseg = np.zeros_like(seg_table)
+  sg = seg_ids.reshape(-1)
+  sok = (sg >= 0) & (sg < seg_table.shape[0])
+  np.add.at(dseg, sg[sok], d[sok])
+  res = dict(word_table=dword, seg_table=dseg, gamma=dgamma, beta=dbeta)
+  if n_patch:
+    res['patch_proj'] = dout[:, patch_start:patch_start + n_patch].copy()
+  if has_pos:
+    res['pos'] = dout.sum(0)
+  return res
