@@ -153,12 +153,12 @@ size_t mmt_embed_workspace_bytes(const mmt_embed_desc* desc);
  *   dword_table[id] += LayerNormBwd(DropoutBwd(dout[row]))   summed over the rows holding id,
  *   dgamma / dbeta (overwritten, or added to with desc->accumulate),
  *   dpatch[b, j] = dout[b, patch_start + j]                   (compact copy for the projection's wgrad GEMM; nullable).
- * `order` = the permutation that sorts word_ids ascending (stable: ties in row order) -- rows with
- * the same id are then adjacent and are summed in that fixed order by ONE wave per id (runs longer
+ * `order` = the permutation that sorts word_ids ascending (stable: ties in row order) and
+ * `sorted_ids[i] = word_ids[order[i]]` -- rows with the same id are then adjacent and are summed in that fixed order by ONE wave per id (runs longer
  * than 32 go through per-32 partial sums), so the scatter needs no atomics and is bitwise reproducible.
  * dword_table is fp32 [vocab, H] and is ACCUMULATED into (the master gradient).  The segment /
  * position table gradients are plain column sums of dout and are left to the caller. */
-int mmt_embed_bwd(const mmt_embed_desc* desc, const void* dout, const int32_t* word_ids,
+int mmt_embed_bwd(const mmt_embed_desc* desc, const void* dout, const int32_t* sorted_ids,
                   const int32_t* order, const float* word_table, const float* gamma, const float* mean,
                   const float* rstd, float* dword_table, float* dgamma, float* dbeta, void* dpatch,
                   void* workspace, size_t workspace_bytes, void* stream);

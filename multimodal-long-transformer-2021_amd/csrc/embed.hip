@@ -31,7 +31,7 @@ struct EmbedParams {
   int S, H, vocab, seg_vocab, patch_start, n_patch;
   float eps, inv_keep;
   uint32_t thresh16, seed_lo, seed_hi;
-  const int *word_ids, *seg_ids, *order;
+  const int *word_ids, *seg_ids, *order, *sorted_ids;   // sorted_ids[i] = word_ids[order[i]]
   const float *word_table, *seg_table, *pos_table, *gamma, *beta, *patch_bias;
   const void* patch;
   void* out;
@@ -132,9 +132,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedParams p) {
     if (lane + 64 * j < nch) load_param(p.gamma + (lane + 64 * j) * 8, gam[j]);
   }
   for (long pos = (long)blockIdx.x * 4 + wave; pos < p.rows; pos += (long)gridDim.x * 4) {
-    const int row0 = p.order[pos];
-    const int id = p.word_ids[row0];
-    const bool first = pos == 0 || p.word_ids[p.order[pos - 1]] != id;
+    const int id = p.sorted_ids[pos];
+    const bool first = pos == 0 || p.sorted_ids[pos - 1] != id;
     if (!first && (pos % kEmbedCut) != 0) continue;
     const long cut = (pos / kEmbedCut + 1) * kEmbedCut;
     const long lim = cut < p.rows ? cut : p.rows;
@@ -148,8 +147,8 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedParams p) {
     }
     long e = pos;
     for (; e < lim; ++e) {
+      if (e != pos && p.sorted_ids[e] != id) break;
       const int row = p.order[e];
-      if (e != pos && p.word_ids[row] != id) break;
       const float mean = p.mean[row], rstd = p.rstd[row];
       const int b = row / p.S, s = row - b * p.S, pj = s - p.patch_start;
       const bool to_patch = p.dpatch != nullptr && (unsigned)pj < (unsigned)p.n_patch;
@@ -188,7 +187,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedParams p) {
         for (int i = 0; i < 8; ++i) acc[j][i] += rstd * (t[j][i] * gam[j][i] - c1 - xh[j][i] * c2);
     }
     // whole run inside this piece -> add to the table row; else park the piece sum in the slab
-    const bool run_ends = e >= p.rows || p.word_ids[p.order[e]] != id;
+    const bool run_ends = e >= p.rows || p.sorted_ids[e] != id;
     const bool whole = first && run_ends;
     if (!id_ok) continue;
 #pragma unroll
@@ -231,10 +230,10 @@ __global__ __launch_bounds__(256) void embed_bwd_runs_kernel(const EmbedParams p
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.H >> 3;
   for (long pos = (long)blockIdx.x * 4 + wave; pos < p.rows; pos += (long)gridDim.x * 4) {
-    const int id = p.word_ids[p.order[pos]];
-    const bool first = pos == 0 || p.word_ids[p.order[pos - 1]] != id;
+    const int id = p.sorted_ids[pos];
+    const bool first = pos == 0 || p.sorted_ids[pos - 1] != id;
     const long cut = (pos / kEmbedCut + 1) * kEmbedCut;
-    if (!first || cut >= p.rows || p.word_ids[p.order[cut]] != id || (unsigned)id >= (unsigned)p.vocab) continue;
+    if (!first || cut >= p.rows || p.sorted_ids[cut] != id || (unsigned)id >= (unsigned)p.vocab) continue;
     float acc[NCH][8];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -242,7 +241,7 @@ __global__ __launch_bounds__(256) void embed_bwd_runs_kernel(const EmbedParams p
       for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
       if (lane + 64 * j < nch) load_param(p.pieces + pos * p.H + (lane + 64 * j) * 8, acc[j]);
     }
-    for (long q = cut; q < p.rows && p.word_ids[p.order[q]] == id; q += kEmbedCut) {
+    for (long q = cut; q < p.rows && p.sorted_ids[q] == id; q += kEmbedCut) {
 #pragma unroll
       for (int j = 0; j < NCH; ++j)
         if (lane + 64 * j < nch) {
@@ -331,16 +330,16 @@ size_t mmt_embed_workspace_bytes(const mmt_embed_desc* d) {
   return ((size_t)mmt::kEmbedBlocks * 2 * d->H + (size_t)d->rows * d->H) * sizeof(float);
 }
 
-int mmt_embed_bwd(const mmt_embed_desc* d, const void* dout, const int32_t* word_ids, const int32_t* order,
+int mmt_embed_bwd(const mmt_embed_desc* d, const void* dout, const int32_t* sorted_ids, const int32_t* order,
                   const float* word_table, const float* gamma, const float* mean, const float* rstd,
                   float* dword_table, float* dgamma, float* dbeta, void* dpatch, void* ws, size_t ws_bytes,
                   void* stream) {
   if (int rc = check_embed(d)) return rc;
-  if (!dout || !word_ids || !order || !word_table || !gamma || !mean || !rstd || !dword_table || !dgamma || !dbeta)
+  if (!dout || !sorted_ids || !order || !word_table || !gamma || !mean || !rstd || !dword_table || !dgamma || !dbeta)
     return mmt::fail(MMT_E_INVALID, "mmt_embed_bwd: NULL argument");
   if (!ws || ws_bytes < mmt_embed_workspace_bytes(d)) return mmt::fail(MMT_E_WORKSPACE, "mmt_embed_bwd: workspace too small");
   mmt::EmbedParams p; fill_embed(p, d);
-  p.dout = dout; p.word_ids = word_ids; p.order = order; p.word_table = word_table; p.gamma = gamma;
+  p.dout = dout; p.sorted_ids = sorted_ids; p.order = order; p.word_table = word_table; p.gamma = gamma;
   p.mean = mean; p.rstd = rstd; p.dword_table = dword_table; p.dpatch = d->n_patch > 0 ? dpatch : nullptr;
   p.part = (float*)ws; p.pieces = p.part + (size_t)mmt::kEmbedBlocks * 2 * d->H;
   p.nblocks = embed_blocks(d);

@@ -38,36 +38,37 @@ struct LayerParams {
 // x_new = x + Dropout(o + bias);  h = LN(x_new)      (RESID)     |    h = LN(x)    (!RESID)
 //   a = o, b = x, p0 = bias, p1 = gamma, p2 = beta, o0 = x_new, o1 = h, s0 = mean, s1 = rstd
 // =============================================================================================
-template <typename T, int NCH, bool RESID, bool HAS_LN>
+template <typename T, int W, int NCH, bool RESID, bool HAS_LN>
 __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const LayerParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nch = p.H >> 3;
+  const int nch = p.H / W;
   const float invH = 1.f / (float)p.H;
   for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
-    float v[NCH][8];
+    float v[NCH][W];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = lane + 64 * j;
       if (c < nch) {
-        const long off = row * p.H + c * 8;
+        const long off = row * p.H + c * W;
         if (RESID) {
-          float o[8], x[8], bs[8];
-          Chunk<T>::load(reinterpret_cast<const T*>(p.a) + off, o);
-          Chunk<T>::load(reinterpret_cast<const T*>(p.b) + off, x);
-          load_param(p.p0 + c * 8, bs);
+          float o[W], x[W], bs[W];
+          ChunkW<T, W>::load(reinterpret_cast<const T*>(p.a) + off, o);
+          ChunkW<T, W>::load(reinterpret_cast<const T*>(p.b) + off, x);
+          load_param_w<W>(p.p0 + c * W, bs);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < W; ++i) {
             float t = o[i] + bs[i];
             if (p.thresh16) t = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
             v[j][i] = x[i] + t;
+            if (sizeof(T) == 2) v[j][i] = (float)(__bf16)v[j][i];      // LayerNorm sees the stored (rounded) x_new
           }
-          Chunk<T>::store(reinterpret_cast<T*>(p.o0) + off, v[j]);
+          ChunkW<T, W>::store(reinterpret_cast<T*>(p.o0) + off, v[j]);
         } else {
-          Chunk<T>::load(reinterpret_cast<const T*>(p.b) + off, v[j]);
+          ChunkW<T, W>::load(reinterpret_cast<const T*>(p.b) + off, v[j]);
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[j][i] = 0.f;
+        for (int i = 0; i < W; ++i) v[j][i] = 0.f;
       }
     }
     if (HAS_LN) {
@@ -75,26 +76,26 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const LayerParams p) 
 #pragma unroll
       for (int j = 0; j < NCH; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += v[j][i];
+        for (int i = 0; i < W; ++i) s += v[j][i];
       const float mean = wave_sum(s) * invH;
       float q = 0.f;
 #pragma unroll
       for (int j = 0; j < NCH; ++j)
         if (lane + 64 * j < nch)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) { const float d = v[j][i] - mean; q += d * d; }
+          for (int i = 0; i < W; ++i) { const float d = v[j][i] - mean; q += d * d; }
       const float rstd = rsqrtf(wave_sum(q) * invH + p.eps);
       if (lane == 0) { p.s0[row] = mean; p.s1[row] = rstd; }
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
         const int c = lane + 64 * j;
         if (c < nch) {
-          float g[8], bt[8], y[8];
-          load_param(p.p1 + c * 8, g);
-          load_param(p.p2 + c * 8, bt);
+          float g[W], bt[W], y[W];
+          load_param_w<W>(p.p1 + c * W, g);
+          load_param_w<W>(p.p2 + c * W, bt);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) y[i] = (v[j][i] - mean) * rstd * g[i] + bt[i];
-          Chunk<T>::store(reinterpret_cast<T*>(p.o1) + row * p.H + c * 8, y);
+          for (int i = 0; i < W; ++i) y[i] = (v[j][i] - mean) * rstd * g[i] + bt[i];
+          ChunkW<T, W>::store(reinterpret_cast<T*>(p.o1) + row * p.H + c * W, y);
         }
       }
     }
@@ -105,88 +106,95 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const LayerParams p) 
 // dX = dx_in + LNbwd(dh);  dx = dX;  do = DropBwd(dX);  partial column sums {dbias, dgamma, dbeta}
 //   a = dx_in (nullable), b = dh, c = x_new (LN input), p1 = gamma, o0 = do, o1 = dx
 // =============================================================================================
-template <typename T, int NCH, bool RESID, bool HAS_LN>
-__global__ __launch_bounds__(256) void resid_ln_bwd_kernel(const LayerParams p) {
-  __shared__ float red[4][64 * NCH * 8];
+template <typename T, int W, int NCH, bool RESID, bool HAS_LN>
+__global__ __launch_bounds__(256, (W * NCH <= 12 ? 4 : 1)) void resid_ln_bwd_kernel(const LayerParams p) {
+  __shared__ float red[4][64 * NCH * W];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nch = p.H >> 3;
+  const int nch = p.H / W;
   const float invH = 1.f / (float)p.H;
-  float acc_b[NCH][8], acc_g[NCH][8], acc_bt[NCH][8];
-  float gam[NCH][8];
+  const bool has_in = p.a != nullptr;
+  float acc_b[NCH][W], acc_g[NCH][W], acc_bt[NCH][W];
+  float gam[NCH][W];
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { acc_b[j][i] = 0.f; acc_g[j][i] = 0.f; acc_bt[j][i] = 0.f; gam[j][i] = 0.f; }
-    if (HAS_LN && lane + 64 * j < nch) load_param(p.p1 + (lane + 64 * j) * 8, gam[j]);
+    for (int i = 0; i < W; ++i) { acc_b[j][i] = 0.f; acc_g[j][i] = 0.f; acc_bt[j][i] = 0.f; gam[j][i] = 0.f; }
+    if (HAS_LN && lane + 64 * j < nch) load_param_w<W>(p.p1 + (lane + 64 * j) * W, gam[j]);
   }
+  // The row's three inputs stay in registers AS LOADED (bf16: W/2 registers per chunk) across the
+  // two wave reductions and are converted twice.
   for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
-    float g[NCH][8], xh[NCH][8], dyh[NCH][8];
+    RawW<T, W> ra[NCH], rb[NCH], rc[NCH];      // dx_in, dh, x_new
     float mean = 0.f, rstd = 0.f;
     if (HAS_LN) { mean = p.mean[row]; rstd = p.rstd[row]; }
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-      const int c = lane + 64 * j;
-      const long off = row * p.H + c * 8;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) { g[j][i] = 0.f; xh[j][i] = 0.f; dyh[j][i] = 0.f; }
-      if (c < nch) {
-        if (p.a) Chunk<T>::load(reinterpret_cast<const T*>(p.a) + off, g[j]);
-        if (HAS_LN) {
-          float dh[8], x[8];
-          Chunk<T>::load(reinterpret_cast<const T*>(p.b) + off, dh);
-          Chunk<T>::load(reinterpret_cast<const T*>(p.c) + off, x);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            xh[j][i] = (x[i] - mean) * rstd;
-            dyh[j][i] = dh[i] * gam[j][i];
-            s1 += dyh[j][i];
-            s2 += dyh[j][i] * xh[j][i];
-            acc_g[j][i] += dh[i] * xh[j][i];
-            acc_bt[j][i] += dh[i];
-          }
-        }
+      const int ch = lane + 64 * j;
+      ra[j].zero(); rb[j].zero(); rc[j].zero();
+      if (ch < nch) {
+        const long off = row * p.H + ch * W;
+        if (has_in) ra[j].load(reinterpret_cast<const T*>(p.a) + off);
+        if (HAS_LN) { rb[j].load(reinterpret_cast<const T*>(p.b) + off); rc[j].load(reinterpret_cast<const T*>(p.c) + off); }
       }
     }
+    float c1 = 0.f, c2 = 0.f;
     if (HAS_LN) {
-      const float c1 = wave_sum(s1) * invH, c2 = wave_sum(s2) * invH;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int j = 0; j < NCH; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) g[j][i] += rstd * (dyh[j][i] - c1 - xh[j][i] * c2);
+        for (int i = 0; i < W; ++i) {
+          const float dh = rb[j].get(i);
+          const float xh = (rc[j].get(i) - mean) * rstd;
+          const float dyh = dh * gam[j][i];
+          s1 += dyh;
+          s2 += dyh * xh;
+          acc_g[j][i] += dh * xh;       // lanes past the row hold zeros (dh = 0)
+          acc_bt[j][i] += dh;
+        }
+      c1 = wave_sum(s1) * invH; c2 = wave_sum(s2) * invH;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) { rb[j].opaque(); rc[j].opaque(); }
     }
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-      const int c = lane + 64 * j;
-      if (c < nch) {
-        const long off = row * p.H + c * 8;
-        float dx[8];
+      const int ch = lane + 64 * j;
+      if (ch < nch) {
+        const long off = row * p.H + ch * W;
+        float dx[W];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dx[i] = g[j][i];
-        Chunk<T>::store(reinterpret_cast<T*>(p.o1) + off, dx);
+        for (int i = 0; i < W; ++i) {
+          float g = ra[j].get(i);
+          if (HAS_LN) {
+            const float xh = (rc[j].get(i) - mean) * rstd;
+            g += rstd * (rb[j].get(i) * gam[j][i] - c1 - xh * c2);
+          }
+          dx[i] = g;
+        }
         if (RESID) {
-          float d_o[8];
+          float d_o[W];
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float t = g[j][i];
+          for (int i = 0; i < W; ++i) {
+            float t = dx[i];
             if (p.thresh16) t = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
             d_o[i] = t;
             acc_b[j][i] += t;
           }
-          Chunk<T>::store(reinterpret_cast<T*>(p.o0) + off, d_o);
+          ChunkW<T, W>::store(reinterpret_cast<T*>(p.o0) + off, d_o);
         }
+        ChunkW<T, W>::store(reinterpret_cast<T*>(p.o1) + off, dx);
       }
     }
   }
   // block-level sums of the three accumulators -> partial slab [block][k][H]
   constexpr int kSets = (RESID ? 1 : 0) + (HAS_LN ? 2 : 0);
   int set = 0;
-  auto flush = [&](float (&acc)[NCH][8]) {
+  auto flush = [&](float (&acc)[NCH][W]) {
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
 #pragma unroll
-      for (int i = 0; i < 8; ++i) red[wave][(lane + 64 * j) * 8 + i] = acc[j][i];
+      for (int i = 0; i < W; ++i) red[wave][(lane + 64 * j) * W + i] = acc[j][i];
     __syncthreads();
     for (int col = threadIdx.x; col < p.H; col += 256)
       p.part[((long)blockIdx.x * kSets + set) * p.H + col] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
@@ -358,6 +366,12 @@ int check_rows(const mmt_rows_desc* d, int max_h) {
   return MMT_OK;
 }
 
+// forward kernels have no per-block partial slab: one row per wave up to 4096 blocks
+int row_blocks_fwd(const mmt_rows_desc* d) {
+  const long need = (d->rows + 3) / 4;
+  return (int)(need < 4096 ? need : 4096);
+}
+
 int row_blocks(const mmt_rows_desc* d) {
   const long need = (d->rows + 3) / 4;
   return (int)(need < kRowBlocks ? need : kRowBlocks);
@@ -373,22 +387,36 @@ void fill(mmt::LayerParams& p, const mmt_rows_desc* d) {
   }
 }
 
+// (chunk width, chunks per lane) for a row length: 4-wide chunks when they tile the row with fewer
+// idle lanes (H = 768: 3 x 4 per lane instead of 2 x 8 with half the lanes idle in the second).
+void row_tiling(int H, int& W, int& nchl) {
+  const int n8 = ((H >> 3) + 63) / 64, n4 = ((H >> 2) + 63) / 64;
+  if (n4 <= 3 && n4 * 256 < n8 * 512) { W = 4; nchl = n4; }
+  else { W = 8; nchl = n8 <= 2 ? n8 : (n8 <= 4 ? 4 : 8); }
+}
+
 template <bool RESID, bool HAS_LN>
 hipError_t launch_fwd(const mmt::LayerParams& p, bool bf16, hipStream_t st, int blocks) {
-  const int nchl = ((p.H >> 3) + 63) / 64;
-#define MMT_FWD(T, N) hipLaunchKernelGGL((mmt::resid_ln_fwd_kernel<T, N, RESID, HAS_LN>), dim3(blocks), dim3(256), 0, st, p)
-  if (bf16) { if (nchl <= 1) MMT_FWD(__bf16, 1); else if (nchl <= 2) MMT_FWD(__bf16, 2); else if (nchl <= 4) MMT_FWD(__bf16, 4); else MMT_FWD(__bf16, 8); }
-  else { if (nchl <= 1) MMT_FWD(float, 1); else if (nchl <= 2) MMT_FWD(float, 2); else if (nchl <= 4) MMT_FWD(float, 4); else MMT_FWD(float, 8); }
+  int W, nchl; row_tiling(p.H, W, nchl);
+#define MMT_FWD(T, WW, N) hipLaunchKernelGGL((mmt::resid_ln_fwd_kernel<T, WW, N, RESID, HAS_LN>), dim3(blocks), dim3(256), 0, st, p)
+#define MMT_FWD_T(T) \
+  if (W == 4) { if (nchl <= 1) MMT_FWD(T, 4, 1); else if (nchl <= 2) MMT_FWD(T, 4, 2); else MMT_FWD(T, 4, 3); } \
+  else { if (nchl <= 1) MMT_FWD(T, 8, 1); else if (nchl <= 2) MMT_FWD(T, 8, 2); else if (nchl <= 4) MMT_FWD(T, 8, 4); else MMT_FWD(T, 8, 8); }
+  if (bf16) { MMT_FWD_T(__bf16) } else { MMT_FWD_T(float) }
+#undef MMT_FWD_T
 #undef MMT_FWD
   return hipGetLastError();
 }
 
 template <bool RESID, bool HAS_LN>
 hipError_t launch_bwd(const mmt::LayerParams& p, bool bf16, hipStream_t st, int blocks) {
-  const int nchl = ((p.H >> 3) + 63) / 64;
-#define MMT_BWD(T, N) hipLaunchKernelGGL((mmt::resid_ln_bwd_kernel<T, N, RESID, HAS_LN>), dim3(blocks), dim3(256), 0, st, p)
-  if (bf16) { if (nchl <= 1) MMT_BWD(__bf16, 1); else if (nchl <= 2) MMT_BWD(__bf16, 2); else MMT_BWD(__bf16, 4); }
-  else { if (nchl <= 1) MMT_BWD(float, 1); else if (nchl <= 2) MMT_BWD(float, 2); else MMT_BWD(float, 4); }
+  int W, nchl; row_tiling(p.H, W, nchl);
+#define MMT_BWD(T, WW, N) hipLaunchKernelGGL((mmt::resid_ln_bwd_kernel<T, WW, N, RESID, HAS_LN>), dim3(blocks), dim3(256), 0, st, p)
+#define MMT_BWD_T(T) \
+  if (W == 4) { if (nchl <= 1) MMT_BWD(T, 4, 1); else if (nchl <= 2) MMT_BWD(T, 4, 2); else MMT_BWD(T, 4, 3); } \
+  else { if (nchl <= 1) MMT_BWD(T, 8, 1); else if (nchl <= 2) MMT_BWD(T, 8, 2); else MMT_BWD(T, 8, 4); }
+  if (bf16) { MMT_BWD_T(__bf16) } else { MMT_BWD_T(float) }
+#undef MMT_BWD_T
 #undef MMT_BWD
   return hipGetLastError();
 }
@@ -412,7 +440,7 @@ int mmt_ln_fwd(const mmt_rows_desc* d, const void* x, const float* gamma, const 
   if (!x || !gamma || !beta || !y || !mean || !rstd) return lfail(MMT_E_INVALID, "mmt_ln_fwd: NULL argument");
   mmt::LayerParams p; fill(p, d);
   p.b = x; p.p1 = gamma; p.p2 = beta; p.o1 = y; p.s0 = mean; p.s1 = rstd;
-  hipError_t e = launch_fwd<false, true>(p, d->dtype == MMT_BF16, (hipStream_t)stream, row_blocks(d));
+  hipError_t e = launch_fwd<false, true>(p, d->dtype == MMT_BF16, (hipStream_t)stream, row_blocks_fwd(d));
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_ln_fwd: %s", hipGetErrorString(e));
 }
 
@@ -442,8 +470,8 @@ int mmt_residual_block_fwd(const mmt_rows_desc* d, const void* o, const float* b
   mmt::LayerParams p; fill(p, d);
   p.a = o; p.b = x; p.p0 = bias; p.p1 = gamma; p.p2 = beta; p.o0 = x_new; p.o1 = h; p.s0 = mean; p.s1 = rstd;
   const bool bf16 = d->dtype == MMT_BF16;
-  hipError_t e = gamma ? launch_fwd<true, true>(p, bf16, (hipStream_t)stream, row_blocks(d))
-                       : launch_fwd<true, false>(p, bf16, (hipStream_t)stream, row_blocks(d));
+  hipError_t e = gamma ? launch_fwd<true, true>(p, bf16, (hipStream_t)stream, row_blocks_fwd(d))
+                       : launch_fwd<true, false>(p, bf16, (hipStream_t)stream, row_blocks_fwd(d));
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_residual_block_fwd: %s", hipGetErrorString(e));
 }
 

@@ -31,6 +31,61 @@ template <> struct Chunk<float> {
     *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
   }
 };
+// ---- W-element chunks (W = 4 | 8) for the row kernels: W is chosen per row length so that the
+// 64 lanes tile the row without idle lanes (H = 768 -> 3 chunks of 4 per lane). ----------------------
+template <typename T, int W> struct ChunkW;
+template <int W> struct ChunkW<__bf16, W> {
+  typedef __attribute__((ext_vector_type(W))) __bf16 vec;
+  static __device__ __forceinline__ void load(const __bf16* p, float (&v)[W]) {
+    const vec t = *reinterpret_cast<const vec*>(p);
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = (float)t[i];
+  }
+  static __device__ __forceinline__ void store(__bf16* p, const float (&v)[W]) {
+    vec t;
+#pragma unroll
+    for (int i = 0; i < W; ++i) t[i] = (__bf16)v[i];
+    *reinterpret_cast<vec*>(p) = t;
+  }
+};
+template <int W> struct ChunkW<float, W> {
+  static __device__ __forceinline__ void load(const float* p, float (&v)[W]) {
+#pragma unroll
+    for (int q = 0; q < W; q += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p + q);
+      v[q] = a[0]; v[q + 1] = a[1]; v[q + 2] = a[2]; v[q + 3] = a[3];
+    }
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[W]) {
+#pragma unroll
+    for (int q = 0; q < W; q += 4) *reinterpret_cast<f32x4*>(p + q) = f32x4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+  }
+};
+// A chunk held as loaded (bf16: W/2 registers instead of W floats) so that a row can stay resident
+// across a reduction at half the register cost.
+template <typename T, int W> struct RawW;
+template <int W> struct RawW<__bf16, W> {
+  typedef __attribute__((ext_vector_type(W))) __bf16 vec;
+  vec v;
+  __device__ __forceinline__ void load(const __bf16* p) { v = *reinterpret_cast<const vec*>(p); }
+  __device__ __forceinline__ void zero() { v = vec{0}; }
+  __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+  // compiler barrier: forget what is known about the converted values, so that they are converted
+  // again after it instead of being kept live as W floats
+  __device__ __forceinline__ void opaque() { asm volatile("" : "+v"(v)); }
+};
+template <int W> struct RawW<float, W> {
+  float v[W];
+  __device__ __forceinline__ void load(const float* p) { ChunkW<float, W>::load(p, v); }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < W; ++i) v[i] = 0.f;
+  }
+  __device__ __forceinline__ float get(int i) const { return v[i]; }
+  __device__ __forceinline__ void opaque() {}
+};
+template <int W> __device__ __forceinline__ void load_param_w(const float* p, float (&v)[W]) { ChunkW<float, W>::load(p, v); }
+
 __device__ __forceinline__ void load_param(const float* p, float (&v)[8]) { Chunk<float>::load(p, v); }
 
 __device__ __forceinline__ float wave_sum(float x) {

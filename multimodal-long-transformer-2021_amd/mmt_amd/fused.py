@@ -336,7 +336,8 @@ class _EmbedAssembleFn(torch.autograd.Function):
     d = ctx.desc
     B, S, H = dout.shape
     dout2 = dout.reshape(B * S, H).contiguous()
-    order = torch.sort(ids, stable=True).indices.to(torch.int32)     # equal ids adjacent, ties in row order
+    srt = torch.sort(ids, stable=True)                                # equal ids adjacent, ties in row order
+    sorted_ids, order = srt.values.contiguous(), srt.indices.to(torch.int32)
     if isinstance(word_table, torch.nn.Parameter) and word_table.requires_grad:
       if word_table.grad is None:
         word_table.grad = torch.zeros_like(word_table, dtype=torch.float32)
@@ -356,7 +357,7 @@ class _EmbedAssembleFn(torch.autograd.Function):
     n = L.mmt_embed_workspace_bytes(d)
     ws = torch.empty((max(n, 16),), dtype=torch.uint8, device=dout.device)
     with torch.cuda.device(dout.device):
-      _lib.check(L.mmt_embed_bwd(d, _p(dout2), _p(ids), _p(order), _p(wt), _p(g32), _p(mean), _p(rstd), _p(dword),
+      _lib.check(L.mmt_embed_bwd(d, _p(dout2), _p(sorted_ids), _p(order), _p(wt), _p(g32), _p(mean), _p(rstd), _p(dword),
                                  _p(dg), _p(db), _p(dpatch), _p(ws), ws.numel(), _stream(dout)))
     dword_ret = None
     if dword is not getattr(word_table, 'grad', None) and ctx.needs_input_grad[2]:
