@@ -18,6 +18,8 @@
 #include "attn_tile.h"
 #include "mmt_err.h"
 
+#include <cstdlib>
+
 namespace mmt {
 
 constexpr int kWgTN = 256;
@@ -36,7 +38,7 @@ struct WgradParams {
   float* bias_part;   // [split, M] partial column sums (slab mode) or NULL -> float atomics into dbias
   long ldy, ldx, ldw;
   int M, N, K;
-  int tiles_n, k_per_split;   // rows per split-K slice (multiple of 32)
+  int tiles_n, tiles_m, k_per_split;   // rows per split-K slice (multiple of 32)
 };
 
 __device__ __forceinline__ int vtile_off(int row, int ch) {      // byte offset inside one 32x128B tile
@@ -200,6 +202,181 @@ __global__ __launch_bounds__(128 * MW, 2) void wgrad_kernel(const WgradParams p)
         atomicAdd(out + (long)(32 * a + kap(i, h)) * p.ldw + 32 * b, acc[a][b][i]);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the 256 x 256 tile (8 waves of 64 x 128): the slabs go global -> LDS with
+// global_load_lds_dwordx4 (no staging registers, no ds_write pass in front of the barrier -- the
+// measured cost of that pass was ~40 % of the loop), 64 rows per step (one barrier per 32 MFMAs per
+// wave instead of 16).  One DMA wave-instruction fills 1 KiB of LDS lane-linearly = 8 rows of one
+// 32 x 128-byte tile, so the tile's swizzle (64-byte halves swapped when bit 1 of the row is set) is
+// applied on the SOURCE side: lane l fetches the 16-byte chunk that belongs at LDS position l.
+// Stage image: [k-slab 0|1][A tiles 0-3 | B tiles 0-3][32 rows x 128 B]  = 64 KiB, double buffered.
+// Needs every split-K slice to be a multiple of 64 rows.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kDmaStageBytes = 2 * 8 * 4096;
+
+// One global_load_lds_dwordx4: lane l's 16 bytes at `gsrc` -> LDS byte address lds_dst + 16 l (M0 = wave-
+// uniform destination, saved and restored).  Issued as asm so that hipcc does not order every later LDS
+// read behind it with a vmcnt(0); completion is counted by hand (vmcnt(0) before the step's barrier).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = lane >> 5, li = lane & 15, cb = (lane >> 4) & 1, r = lane & 31;
+  // XCD-aware order: blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8); XCD x takes the
+  // x-th contiguous range of the list ordered (split-K slice, row tile, column tile), so that the workgroups
+  // sharing one L2 read the same K rows and mostly the same dy / x column slabs (each slab ~once per L2
+  // instead of once per workgroup -- the L2-miss traffic, not the MFMA rate, bounded this kernel).
+  int ks, tm, tn;
+  {
+    const int nwg = gridDim.x, b = blockIdx.x, x = b & 7;
+    const int base = nwg >> 3, rem = nwg & 7;                       // XCD y holds base + (y < rem) blocks
+    const int L = x * base + min(x, rem) + (b >> 3);
+    const int tiles = p.tiles_n * p.tiles_m;
+    ks = L / tiles;
+    const int t = L - ks * tiles;
+    tm = t / p.tiles_n; tn = t - tm * p.tiles_n;
+  }
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int k_begin = ks * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int n_steps = (k_end - k_begin) >> 6;
+  if (n_steps <= 0) return;
+
+  // ---- DMA map: wave w issues instructions w*8 .. w*8+7 of the stage; instruction idx = (kslab*8 + tile8)*4 + rowgroup
+  const int drow = lane >> 3, dpos = lane & 7;                 // row inside the 8-row group, 16-byte position in the LDS row
+  const __bf16* gsrc[8];
+  int ldst[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int idx = wave * 8 + j;
+    const int kslab = idx >> 5, tile8 = (idx >> 2) & 7, rg = idx & 3;
+    const int row = rg * 8 + drow;                             // row inside the tile
+    const int ch = (((dpos >> 2) ^ ((row >> 1) & 1)) << 2) | (dpos & 3);    // logical chunk stored at this LDS position
+    const long krow = k_begin + kslab * 32 + row;
+    gsrc[j] = tile8 < 4 ? p.dy + krow * p.ldy + m0 + tile8 * 64 + ch * 8
+                        : p.x + krow * p.ldx + n0 + (tile8 - 4) * 64 + ch * 8;
+    ldst[j] = idx * 1024;
+  }
+  const long astep = 64 * p.ldy, bstep = 64 * p.ldx;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  auto dma = [&](unsigned stage, int step) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tile8 = ((wave * 8 + j) >> 2) & 7;
+      const __bf16* g = gsrc[j] + (long)step * (tile8 < 4 ? astep : bstep);
+      glds16(g, stage + ldst[j]);
+    }
+  };
+
+  const int frow = 4 * h + (li >> 2);
+  int fo[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db) fo[db] = frow * 128 + ((db ^ ((frow >> 1) & 1)) << 6) + 32 * cb + 8 * (li & 3);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int a_tile = wm * 4096, b_tile = 4 * 4096 + wn * 2 * 4096;
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x16{0};
+  // bias gradient: the tn == 0 workgroups sum the dy slab out of LDS; thread -> logical chunk (tid & 31)
+  // of the 256 columns, rows (tid >> 5) + 16 v
+  const bool do_bias = p.dbias != nullptr && tn == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int bch = tid & 31, brow0 = tid >> 5;
+
+  dma(lds0, 0);
+  wait_dma();
+  __syncthreads();
+
+  for (int step = 0; step < n_steps; ++step) {
+    unsigned char* cur = smem + (step & 1) * kDmaStageBytes;
+    if (step + 1 < n_steps) dma(lds0 + ((step + 1) & 1) * kDmaStageBytes, step + 1);         // lands during this step's MFMAs
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const unsigned char* slab = cur + (s >> 1) * (8 * 4096) + (s & 1) * 2048;
+      bf16x8 af[2], bfr[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const unsigned char* base = slab + a_tile + fo[a];
+        const bf16x4 lo = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base)));
+        const bf16x4 hi = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 1024)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { af[a][j] = lo[j]; af[a][4 + j] = hi[j]; }
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const unsigned char* base = slab + b_tile + (b >> 1) * 4096 + fo[b & 1];
+        const bf16x4 lo = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base)));
+        const bf16x4 hi = __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 1024)));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bfr[b][j] = lo[j]; bfr[b][4 + j] = hi[j]; }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = brow0 + 16 * v;                  // 0..63
+        const int rt = row & 31, t4 = bch >> 3, c8 = bch & 7;
+        const unsigned char* src = cur + (row >> 5) * (8 * 4096) + t4 * 4096 + rt * 128 +
+                                   ((((c8 >> 2) ^ ((rt >> 1) & 1))) << 6) + (c8 & 3) * 16;
+        const bf16x8 t = *reinterpret_cast<const bf16x8*>(src);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += (float)t[j];
+      }
+    }
+    wait_dma();                            // the DMA into the other buffer has landed
+    __syncthreads();
+  }
+
+  if (do_bias) {       // 16 row groups x 256 columns through the (now idle) staging LDS, fixed order
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[brow0 * 256 + bch * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 256) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) t += red[g * 256 + tid];
+      if (p.bias_part) p.bias_part[(long)ks * p.M + m0 + tid] = t;
+      else atomicAdd(p.dbias + m0 + tid, t);
+    }
+  }
+
+  if (p.slabs) {
+    float* out = p.slabs + (long)ks * p.M * p.N + (long)(m0 + wm * 64) * p.N + n0 + wn * 128 + r;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          out[(long)(32 * a + kap(i, h)) * p.N + 32 * b] = acc[a][b][i];
+    return;
+  }
+  float* out = p.dw + (long)(m0 + wm * 64) * p.ldw + n0 + wn * 128 + r;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        atomicAdd(out + (long)(32 * a + kap(i, h)) * p.ldw + 32 * b, acc[a][b][i]);
+}
+
 // dw[m][n] += sum_s slabs[s][m][n]   (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* dw, long ldw, const float* slabs, int split, int M, int N,
                                                            float* dbias, const float* bias_part) {
@@ -263,10 +440,12 @@ extern "C" int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, c
   p.ldy = ldy; p.ldx = ldx; p.ldw = ldw; p.M = M; p.N = N; p.K = (int)K;
   const int tile_m = wgrad_tile_m(M);
   const int tiles_m = M / tile_m;
-  p.tiles_n = N / mmt::kWgTN;
+  p.tiles_n = N / mmt::kWgTN; p.tiles_m = tiles_m;
   const int tiles = tiles_m * p.tiles_n;
   int split = wgrad_split(tiles, K, tile_m);
-  const int kps = (int)(((K + split - 1) / split + 31) / 32 * 32);
+  const bool dma = tile_m == 256 && (K % 64) == 0 && !getenv("MMT_WGRAD_NODMA");
+  const int kq = dma ? 64 : 32;            // rows per main-loop step
+  const int kps = (int)(((K + split - 1) / split + kq - 1) / kq * kq);
   split = (int)((K + kps - 1) / kps);
   p.k_per_split = kps;
   const size_t need = (size_t)split * ((size_t)M * N + M) * sizeof(float);
@@ -274,7 +453,11 @@ extern "C" int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, c
   p.dbias = dbias;
   p.bias_part = (p.slabs && dbias) ? p.slabs + (size_t)split * M * N : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  if (tile_m == 256) {
+  if (dma) {
+    const int lds = 2 * mmt::kDmaStageBytes;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmt::wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(mmt::wgrad_dma_kernel, dim3(tiles * split), dim3(512), lds, st, p);
+  } else if (tile_m == 256) {
     const int lds = 2 * mmt::WgCfg<4>::kStageBytes;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmt::wgrad_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(mmt::wgrad_kernel<4>, dim3(tiles, split), dim3(512), lds, st, p);

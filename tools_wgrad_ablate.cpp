@@ -1,0 +1,26 @@
+// Dev tool: standalone hipEvent timing of mmt_wgrad_accumulate (M=3072, N=768, K=16384) without Python:
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Iinclude -DVARIANT='"name"' tools_wgrad_ablate.cpp -o _ab/wg && ./_ab/wg
+// Ablations (drop the DMA issue / the barrier / the MFMAs) were done by editing the kernel locally; DESIGN.md has the numbers.
+#include <cstdarg>
+#include <cstdio>
+#include <vector>
+#include "multimodal-long-transformer-2021_amd/csrc/wgrad_gemm.hip"
+namespace mmt { int fail(int code, const char* fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; } }
+int main() {
+  const int M = 3072, N = 768; const long K = 16384;
+  __bf16 *dy, *x; float *dw, *ws;
+  hipMalloc(&dy, K * M * 2); hipMalloc(&x, K * N * 2); hipMalloc(&dw, (size_t)M * N * 4);
+  size_t wsb = mmt_wgrad_workspace_bytes(M, N, K); hipMalloc(&ws, wsb);
+  std::vector<unsigned short> h(K * M); for (size_t i = 0; i < h.size(); ++i) h[i] = 0x3c00 + (i * 2654435761u >> 20) % 512;
+  hipMemcpy(dy, h.data(), K * M * 2, hipMemcpyHostToDevice); hipMemcpy(x, h.data(), K * N * 2, hipMemcpyHostToDevice);
+  hipMemset(dw, 0, (size_t)M * N * 4);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 5; ++i) mmt_wgrad_accumulate(dw, N, dy, M, x, N, M, N, K, ws, wsb, nullptr);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  for (int i = 0; i < 20; ++i) mmt_wgrad_accumulate(dw, N, dy, M, x, N, M, N, K, ws, wsb, nullptr);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  printf("%s: %.1f us per call (kernel + reduce)\n", VARIANT, ms * 1000 / 20);
+  return 0;
+}
