@@ -86,6 +86,7 @@ class GradientBucketReducer:
     self.layout = []            # (param, bucket index, element offset) for flat optimizers
     self.buckets_are_zero = True
     self._bucket_of, self._pending, self._handles = {}, [], []
+    self._ready = set()         # parameters already counted in this (armed) backward
     order = list(reversed(self.params))
     cur, cur_bytes = [], 0
     groups = []
@@ -112,7 +113,11 @@ class GradientBucketReducer:
     if self.world > 1:
       for p in self.params:
         p.register_post_accumulate_grad_hook(self._on_grad_ready)
-        # parameters whose gradient arrives through layers._CastParamFn bypass AccumulateGrad
+        # Kernels that add a gradient straight into `.grad` (weight-gradient GEMM, fused-layer column
+        # sums, relative tables, `_CastParamFn`) return None to autograd and call these hooks themselves
+        # once the write is enqueued.  Depending on the torch version the parameter's AccumulateGrad
+        # node still runs its post-accumulate hook for such an undefined gradient (it does on 2.10), so
+        # `_on_grad_ready` counts every parameter at most once per backward.
         p._mmt_grad_ready_hooks = (self._on_grad_ready,)
 
   def zero_grad(self):
@@ -122,6 +127,7 @@ class GradientBucketReducer:
     self.buckets_are_zero = False
     self._pending = list(self._group_sizes)
     self._handles = []
+    self._ready = set()
     self.armed = True
 
   def set_armed(self, armed: bool):
@@ -130,8 +136,9 @@ class GradientBucketReducer:
     self.armed = bool(armed)
 
   def _on_grad_ready(self, p):
-    if not self.armed:
+    if not self.armed or id(p) in self._ready:
       return
+    self._ready.add(id(p))
     gi = self._bucket_of[p]
     self._pending[gi] -= 1
     if self._pending[gi] == 0:
@@ -141,6 +148,7 @@ class GradientBucketReducer:
     """Waits for the outstanding all-reduces and applies the mean (if requested)."""
     if self.world > 1:
       for gi, left in enumerate(self._pending):     # parameters that received no gradient
+        assert left >= 0, 'gradient-ready accounting went negative'
         if left > 0:
           self._handles.append(dist.all_reduce(self.buckets[gi], op=dist.ReduceOp.SUM, async_op=True))
       for h in self._handles:
@@ -149,6 +157,7 @@ class GradientBucketReducer:
         for b in self.buckets:
           b.mul_(1.0 / self.world)
     self._handles = []
+    self._ready = set()
 
   def clip_by_global_norm(self, max_norm: float, apply: bool = True) -> torch.Tensor:
     """Returns the clip factor min(1, max_norm / ||g||) as a device scalar; with apply=False the
