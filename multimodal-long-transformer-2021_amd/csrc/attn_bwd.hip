@@ -592,8 +592,8 @@ __global__ __launch_bounds__(1024) void drel_reduce_kernel(const BwdParams p) {
   const int id = blockIdx.x, n = blockIdx.y, d = threadIdx.x & 63, part = threadIdx.x >> 6;
   if (id >= p.R) return;
   const int per = p.Rp * 64 + p.Rp;
-  const int waves_per_bn = ((p.S + 127) >> 7) * 4;
-  const int live = (p.S + 31) >> 5;               // waves past the end of the sequence wrote nothing
+  const int waves_per_bn = p.red_per_plane;       // partial slots per plane (one per wave, or per workgroup)
+  const int live = p.red_live;                    // slots past the end of the sequence were not written
   const int total = p.B * live;
   const int chunk = (total + 15) >> 4;
   const int lo = part * chunk, hi = min(total, lo + chunk);
@@ -639,7 +639,10 @@ static void allow_lds(K kernel, int bytes) {
 }
 
 template <typename T, int MODE, int Rp, bool GEN>
-static hipError_t launch_bwd_one(const BwdParams& p, hipStream_t st) {
+static hipError_t launch_bwd_one(const BwdParams& p_in, hipStream_t st) {
+  BwdParams p = p_in;
+  p.red_per_plane = ((p.S + 127) >> 7) * 4;               // one dE partial per wave (32 rows)
+  p.red_live = (p.S + 31) >> 5;
   const int per_bn = (p.n_chunks * p.n_gblk + 3) / 4;
   dim3 grid(p.n_band_blocks + (MODE == kBand ? per_bn * p.B * p.N : 0));
   const int lds_a = 4 * BwdLds<T, Rp>::kDq, lds_b = 4 * BwdLds<T, Rp>::kDkv;

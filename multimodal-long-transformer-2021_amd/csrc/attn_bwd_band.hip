@@ -285,41 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   }
 
   if (HAS_REL) {
-    // (1) this wave's share of dE^T[d x id] and dbias[id] (lane = id)
-    {
-      bf16x8 qt[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) qt[u] = buf16(rq, (unsigned)(lane >> 3) * qs1b + (lane & 7) * 16, (unsigned)(q0 + 8 * u) * qs1b);
-      tile_to_lds(xlds, qt, lane);
-      wave_lds_sync();
-      const int widx = band_wg * 4 + wave;
-      float* pe = p.part_red + (long)widx * (Rp * 64 + Rp);
-#pragma unroll
-      for (int rb = 0; rb < Rp / 32; ++rb) {
-        const int id = rb * 32 + r;
-        const int col = tcol(1, m, id);
-        float vals[16], bsum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int qq = q0 + kap(i, h);
-          const bool use = id < p.R && qq < p.S && !(p.skip_global && is_global(p.pat, qq));
-          vals[i] = use ? dtab[kap(i, h) * kTStride(Rp) + col] : 0.f;
-          bsum += vals[i];
-        }
-        bsum = half_sum(bsum);
-        f32x16 e0 = {0}, e1 = {0};
-        mma_xt_hilo(e0, e1, VTile<T>{}, xlds, vals, lane);
-        float* row = pe + (long)id * 64;
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-          *reinterpret_cast<f32x4*>(row + 8 * gi + 4 * h) = f32x4{e0[4 * gi], e0[4 * gi + 1], e0[4 * gi + 2], e0[4 * gi + 3]};
-          *reinterpret_cast<f32x4*>(row + 32 + 8 * gi + 4 * h) = f32x4{e1[4 * gi], e1[4 * gi + 1], e1[4 * gi + 2], e1[4 * gi + 3]};
-        }
-        if (h == 0) pe[Rp * 64 + id] = bsum;
-      }
-      wave_lds_sync();
-    }
-    // (2) dQ^T += E^T[d x id] . dRel^T[id x q]
+    // (1) dQ^T += E^T[d x id] . dRel^T[id x q]
     const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
     const unsigned es1b = (unsigned)p.N * 128;
     const auto re = make_rsrc(Eb, (unsigned)(p.R - 1) * es1b + 128);
@@ -340,16 +306,61 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
       wave_lds_sync();
     }
   }
-  if (!q_ok || (p.skip_global && is_global(p.pat, q))) return;
-  T* DQ = reinterpret_cast<T*>(p.dq) + (long)b * p.qs[0] + (long)q * p.qs[1] + (long)n * p.qs[2];
+  if (q_ok && !(p.skip_global && is_global(p.pat, q))) {
+    T* DQ = reinterpret_cast<T*>(p.dq) + (long)b * p.qs[0] + (long)q * p.qs[1] + (long)n * p.qs[2];
 #pragma unroll
-  for (int gi = 0; gi < 4; ++gi) {
-    const int d = 8 * gi + 4 * h;
-    bf16x4 x, y;
+    for (int gi = 0; gi < 4; ++gi) {
+      const int d = 8 * gi + 4 * h;
+      bf16x4 x, y;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { x[j] = (__bf16)a0[4 * gi + j]; y[j] = (__bf16)a1[4 * gi + j]; }
-    *reinterpret_cast<bf16x4*>(DQ + d) = x;
-    *reinterpret_cast<bf16x4*>(DQ + 32 + d) = y;
+      for (int j = 0; j < 4; ++j) { x[j] = (__bf16)a0[4 * gi + j]; y[j] = (__bf16)a1[4 * gi + j]; }
+      *reinterpret_cast<bf16x4*>(DQ + d) = x;
+      *reinterpret_cast<bf16x4*>(DQ + 32 + d) = y;
+    }
+  }
+  if (!HAS_REL) return;
+
+  // (2) the workgroup's share of dE^T[d x id] = Q^T . dRel and dbias[id]: every wave leaves its Q tile next
+  //     to its dRel table in LDS, then wave 0 contracts all (up to) 128 query rows -- one partial per
+  //     workgroup instead of one per wave for the fixed-order reduce (K4c reads 4x less).
+  {
+    bf16x8 qt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) qt[u] = buf16(rq, (unsigned)(lane >> 3) * qs1b + (lane & 7) * 16, (unsigned)(q0 + 8 * u) * qs1b);
+    tile_to_lds(xlds, qt, lane);
+  }
+  __syncthreads();                 // waves past the end of the sequence have exited and are not waited for
+  if (wave != 0) return;
+  float* pe = p.part_red + (long)band_wg * (Rp * 64 + Rp);
+#pragma unroll
+  for (int rb = 0; rb < Rp / 32; ++rb) {
+    const int id = rb * 32 + r;
+    const int col = tcol(1, m, id);
+    f32x16 e0 = {0}, e1 = {0};
+    float bsum = 0.f;
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const int q0w = q0 + 32 * w2;
+      if (q0w >= p.S) break;
+      const float* dtab_w = reinterpret_cast<const float*>(smem + w2 * L::kDq + L::kTab);
+      const unsigned char* xlds_w = smem + w2 * L::kDq + 2 * L::kTab;
+      float vals[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qq = q0w + kap(i, h);
+        const bool use = id < p.R && qq < p.S && !(p.skip_global && is_global(p.pat, qq));
+        vals[i] = use ? dtab_w[kap(i, h) * kTStride(Rp) + col] : 0.f;
+        bsum += vals[i];
+      }
+      mma_xt_hilo(e0, e1, VTile<T>{}, xlds_w, vals, lane);
+    }
+    bsum = half_sum(bsum);
+    float* row = pe + (long)id * 64;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      *reinterpret_cast<f32x4*>(row + 8 * gi + 4 * h) = f32x4{e0[4 * gi], e0[4 * gi + 1], e0[4 * gi + 2], e0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(row + 32 + 8 * gi + 4 * h) = f32x4{e1[4 * gi], e1[4 * gi + 1], e1[4 * gi + 2], e1[4 * gi + 3]};
+    }
+    if (h == 0) pe[Rp * 64 + id] = bsum;
   }
 }
 
@@ -589,7 +600,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
 
 // ------------------------------------ launcher --------------------------------------------
 template <int Rp, bool HAS_REL>
-static hipError_t launch_lean(const BwdParams& p, hipStream_t st) {
+static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
+  BwdParams p = p_in;
+  p.red_per_plane = p.red_live = (p.S + 127) >> 7;        // one dE partial per 128-row workgroup
   const int per_bn = (p.n_chunks * p.n_gblk + 3) / 4;
   dim3 grid(p.n_band_blocks + per_bn * p.B * p.N);
   const int lds_a = 4 * LeanLds<Rp>::kDq, lds_b = 4 * LeanLds<Rp>::kDkv;
