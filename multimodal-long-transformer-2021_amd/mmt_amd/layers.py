@@ -138,6 +138,36 @@ def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor])
   return F.linear(x, cast_param(weight, x.dtype), None if bias is None else cast_param(bias, x.dtype))
 
 
+class _TiedLogitsFn(torch.autograd.Function):
+  """logits = x @ table^T + bias against the (tied) word table: the forward reads the bf16 shadow
+  table the optimizer maintains (no 94 MB fp32 -> bf16 cast per step), the backward adds
+  dlogits^T @ x into the fp32 master gradient with one mixed-precision accumulate (no cast + add
+  pair).  It returns None for the table and does NOT run the gradient-ready hooks: the table's own
+  AccumulateGrad node fires them once, after the embedding lookup's backward has added its part."""
+
+  @staticmethod
+  def forward(ctx, x, table, bias):
+    w = _param_weight(table, x.dtype)
+    b = None if bias is None else _param_weight(bias, x.dtype)
+    ctx.save_for_backward(x, w)
+    ctx.params = (table, bias)
+    return F.linear(x, w, b)
+
+  @staticmethod
+  def backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    table, bias = ctx.params
+    dx = torch.mm(dy, w) if ctx.needs_input_grad[0] else None
+    if table.requires_grad:
+      if table.grad is None:
+        table.grad = torch.zeros_like(table, dtype=torch.float32)
+      fused.accumulate_grad_(table.grad, torch.mm(dy.t(), x))
+    db = None
+    if bias is not None and bias.requires_grad:
+      db = dy.sum(0, dtype=torch.float32).to(bias.dtype)
+    return dx, None, db
+
+
 class EmbeddingLookup(nn.Module):
   """etc_layers.EmbeddingLookup (ctor args as at `mmt_encoder.py:90-95`): table [V,E], an
   optional projection when projection_size != embedding_size.  One-hot and gather lookups
@@ -365,7 +395,12 @@ class MaskedLM(nn.Module):
                      self.layer_norm.bias.to(x.dtype), self.layer_norm.eps)
     # the tied table also receives the embedding-lookup gradient through plain autograd, so it
     # must not use the accumulate-in-backward cast (one gradient-ready event per parameter)
-    logits = F.linear(x, self.embedding_table.to(x.dtype), cast_param(self.output_bias, x.dtype))
+    table = self.embedding_table
+    if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and torch.is_grad_enabled()
+        and isinstance(table, nn.Parameter) and table.dtype == torch.float32 and table.requires_grad):
+      logits = _TiedLogitsFn.apply(x, table, self.output_bias)
+    else:
+      logits = F.linear(x, table.to(x.dtype), cast_param(self.output_bias, x.dtype))
     return logits.view(masked_positions.shape[0], masked_positions.shape[1], -1)
 
 
