@@ -19,7 +19,9 @@ _seed_counter = itertools.count(1)
 
 
 def next_seed(base: int = 0) -> int:
-  return (int(base) * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & ((1 << 64) - 1)
+  # 63 bits: the seed travels through autograd.Function.apply as a Python int, which torch's
+  # shape-recording profiler converts to int64
+  return (int(base) * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & ((1 << 63) - 1)
 
 
 def _desc(x2d: torch.Tensor, eps=1e-12, p=0.0, seed=0) -> _lib.RowsDesc:

@@ -356,6 +356,17 @@ class RelativeTransformerLayers(nn.Module):
     return x
 
 
+def gather_rows_merged(sequence_tensor: torch.Tensor, position_sets):
+  """One index_select for several heads: `position_sets` is a list of [B,M_i] position tensors
+  (gather_indexes semantics each); returns the list of [B*M_i, W] row blocks.  One gather forward
+  and ONE dense scatter (zero-fill + index_add) backward instead of one per head."""
+  B, S, W = sequence_tensor.shape
+  offs = (torch.arange(B, device=sequence_tensor.device) * S).view(-1, 1)
+  flat = [(p.long() + offs).reshape(-1) for p in position_sets]
+  rows = sequence_tensor.reshape(B * S, W).index_select(0, torch.cat(flat))
+  return list(torch.split(rows, [f.numel() for f in flat]))
+
+
 def gather_indexes(sequence_tensor: torch.Tensor, positions: torch.Tensor) -> torch.Tensor:
   """`src/tensor_utils.py:27-44`: [B,S,W], [B,M] -> [B*M, W]."""
   B, S, W = sequence_tensor.shape
@@ -386,8 +397,9 @@ class MaskedLM(nn.Module):
   def embedding_table(self):
     return self._embedding_layer[0].embedding_table if self._embedding_layer else self.mlm_embedding_table
 
-  def forward(self, sequence_data, masked_positions):
-    x = gather_indexes(sequence_data, masked_positions)
+  def forward(self, sequence_data, masked_positions, gathered=None):
+    # `gathered`: rows already picked by the caller's single merged gather (models.py)
+    x = gather_indexes(sequence_data, masked_positions) if gathered is None else gathered
     x = _linear(x, self.dense_weight, self.dense_bias)
     if self.activation is not None:
       x = self.activation(x)
@@ -420,8 +432,8 @@ class MaskedPP(nn.Module):
     self.bias = nn.Parameter(torch.zeros(output_num_classes))
     self.activation = activation
 
-  def forward(self, sequence_data, masked_positions):
-    x = gather_indexes(sequence_data, masked_positions)
+  def forward(self, sequence_data, masked_positions, gathered=None):
+    x = gather_indexes(sequence_data, masked_positions) if gathered is None else gathered
     x = F.layer_norm(x, self.layer_norm.normalized_shape, self.layer_norm.weight.to(x.dtype),
                      self.layer_norm.bias.to(x.dtype), self.layer_norm.eps)
     x = _linear(x, self.dense_weight, self.dense_bias)
@@ -453,8 +465,8 @@ class ClassificationHead(nn.Module):
     nn.init.xavier_uniform_(self.out_proj_weight)
     self.out_proj_bias = nn.Parameter(torch.zeros(num_classes))
 
-  def forward(self, features, training=False):
-    x = features[:, self.cls_token_idx]
+  def forward(self, features, training=False, gathered=None):
+    x = features[:, self.cls_token_idx] if gathered is None else gathered
     x = F.dropout(x, self.dropout_rate, training)
     if self.dense_weight is not None:
       x = _linear(x, self.dense_weight, self.dense_bias)

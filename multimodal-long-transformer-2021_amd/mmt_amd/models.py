@@ -5,6 +5,7 @@ from __future__ import annotations
 
 from typing import List, Optional
 
+import torch
 import torch.nn as nn
 
 from . import layers
@@ -43,12 +44,23 @@ class MmtPretrainingModel(nn.Module):
                                 patch_embeddings=patch_embeddings, training=training,
                                 attention_pattern=attention_pattern, valid_len=valid_len))
     seq = outputs['sequence_output']
+    # every head reads a few rows of the sequence output: pick them with one merged gather
+    B = seq.shape[0]
+    sets, names = [], []
     if mlm_positions is not None:
-      outputs['mlm_logits'] = self.masked_lm(seq, masked_positions=mlm_positions)
+      sets.append(mlm_positions); names.append('/mlm')
     if mpp_positions is not None:
-      outputs['mpp_logits'] = self.masked_pp(seq, masked_positions=mpp_positions)
+      sets.append(mpp_positions); names.append('/mpp')
     for head in self.classification_heads:
-      outputs[f'{head.name}_logits'] = head(seq, training=bool(training))
+      sets.append(torch.full((B, 1), head.cls_token_idx, dtype=torch.long, device=seq.device))
+      names.append(head.name)
+    rows = dict(zip(names, layers.gather_rows_merged(seq, sets))) if sets else {}
+    if mlm_positions is not None:
+      outputs['mlm_logits'] = self.masked_lm(seq, masked_positions=mlm_positions, gathered=rows['/mlm'])
+    if mpp_positions is not None:
+      outputs['mpp_logits'] = self.masked_pp(seq, masked_positions=mpp_positions, gathered=rows['/mpp'])
+    for head in self.classification_heads:
+      outputs[f'{head.name}_logits'] = head(seq, training=bool(training), gathered=rows[head.name])
     return outputs
 
   @property
