@@ -102,21 +102,25 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
   // ---- relative-score table (log2 domain), bias row through LDS -----------------------------
   float relfn = 0.f, relfp = 0.f;     // the two clipped columns of this lane's row
   if (HAS_REL) {
-    float* bias_ts = reinterpret_cast<float*>(vlds);
-    if (lane < Rp)
-      bias_ts[lane] = (p.bias && lane < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)lane * p.N + n] * p.tscale : 0.f;
+    // all global loads of the prologue are issued before anything waits: E fragments first, then the bias
+    // row (its LDS round trip used to sit in front of the E loads: one extra memory latency per wave)
     const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
     const unsigned es1b = (unsigned)p.N * 128;
     const auto re = make_rsrc(Eb, (unsigned)(p.R - 1) * es1b + 128);
+    Frag<T> ef[Rp / 32];
+#pragma unroll
+    for (int rb = 0; rb < Rp / 32; ++rb)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) ef[rb].v[s] = buf16(re, (unsigned)r * es1b + 64 * h + 16 * s, (unsigned)(rb * 32) * es1b);
+    float* bias_ts = reinterpret_cast<float*>(vlds);
+    if (lane < Rp)
+      bias_ts[lane] = (p.bias && lane < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)lane * p.N + n] * p.tscale : 0.f;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int rb = 0; rb < Rp / 32; ++rb) {
-      Frag<T> ef;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) ef.v[s] = buf16(re, (unsigned)r * es1b + 64 * h + 16 * s, (unsigned)(rb * 32) * es1b);
       f32x16 c = {0};
-      c = mma_rows(ef, qf, c);   // [id x q]
+      c = mma_rows(ef[rb], qf, c);   // [id x q]
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int id = rb * 32 + kap(i, h);
