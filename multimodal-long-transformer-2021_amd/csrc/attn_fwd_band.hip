@@ -173,53 +173,47 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
     const int dbase = k0 - q + 4 * h;
 
     float pr[16], s2[16];
-    const bool cls_a = plain && one_id;
-    float tmax;
-    if (cls_a) {                                               // ---- class A
-      float cm = fmaxf(fmaxf(c[0], c[1]), c[2]);
+    if (plain && one_id) {                                     // ---- class A
 #pragma unroll
-      for (int i = 3; i < 15; i += 2) cm = fmaxf(fmaxf(cm, c[i]), c[i + 1]);
-      cm = fmaxf(cm, c[15]);
-      tmax = fmaf(cm, p.sscale, relc);
-    } else {
-      if (plain) {                                             // ---- class B (HAS_REL, mixed ids)
-        const int abase = trow_addr + 4 * (m + dbase), alo = trow_addr, ahi = trow_addr + 8 * m;
+      for (int i = 0; i < 16; ++i) s2[i] = fmaf(c[i], p.sscale, relc);
+    } else if (plain) {                                        // ---- class B (HAS_REL, mixed ids)
+      const int abase = trow_addr + 4 * (m + dbase), alo = trow_addr, ahi = trow_addr + 8 * m;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int a = med3i(abase + 4 * ((i & 3) + 8 * (i >> 2)), alo, ahi);
-          s2[i] = fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)a);
-        }
-      } else if (in_range && seg_all && no_gkey && one_id) {   // ---- class D (band edge)
-        const unsigned W2 = 2u * (unsigned)W;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const unsigned dd = (unsigned)(dbase + (i & 3) + 8 * (i >> 2) + W);
-          s2[i] = fmaf(c[i], p.sscale, relc) + (dd <= W2 ? 0.f : p.mask_add);
-        }
-      } else {                                                 // ---- class C (general)
-        const int kb = k0 + 4 * h;
-        const bool qv = q < valid_len;
-        const unsigned W2 = 2u * (unsigned)W;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int ci = (i & 3) + 8 * (i >> 2);
-          const int kk = kb + ci, d = dbase + ci;
-          const bool near = ignore_band | ((unsigned)(d + W) <= W2);
-          const bool gk = (unsigned)(kk - p.pat.g0) < (unsigned)p.pat.ng;
-          const bool seg = (kk < valid_len) == qv;
-          const bool keep = (int)seg & ((int)near | (int)gk);
-          float rel = 0.f;
-          if (HAS_REL) rel = trow[min(max(d, -m), m) + m];
-          float s = fmaf(c[i], p.sscale, rel);
-          s = keep ? s : s + p.mask_add;
-          s2[i] = kk < p.S ? s : -INFINITY;
-        }
+      for (int i = 0; i < 16; ++i) {
+        const int a = med3i(abase + 4 * ((i & 3) + 8 * (i >> 2)), alo, ahi);
+        s2[i] = fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)a);
       }
-      tmax = fmaxf(fmaxf(s2[0], s2[1]), s2[2]);
+    } else if (in_range && seg_all && no_gkey && one_id) {     // ---- class D (band edge)
+      const unsigned W2 = 2u * (unsigned)W;
 #pragma unroll
-      for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s2[i]), s2[i + 1]);
-      tmax = fmaxf(tmax, s2[15]);
+      for (int i = 0; i < 16; ++i) {
+        const unsigned dd = (unsigned)(dbase + (i & 3) + 8 * (i >> 2) + W);
+        s2[i] = fmaf(c[i], p.sscale, relc) + (dd <= W2 ? 0.f : p.mask_add);
+      }
+    } else {                                                   // ---- class C (general)
+      const int kb = k0 + 4 * h;
+      const bool qv = q < valid_len;
+      const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2);
+        const int kk = kb + ci, d = dbase + ci;
+        const bool near = ignore_band | ((unsigned)(d + W) <= W2);
+        const bool gk = (unsigned)(kk - p.pat.g0) < (unsigned)p.pat.ng;
+        const bool seg = (kk < valid_len) == qv;
+        const bool keep = (int)seg & ((int)near | (int)gk);
+        float rel = 0.f;
+        if (HAS_REL) rel = trow[min(max(d, -m), m) + m];
+        float s = fmaf(c[i], p.sscale, rel);
+        s = keep ? s : s + p.mask_add;
+        s2[i] = kk < p.S ? s : -INFINITY;
+      }
     }
+    // one definition of s2 / pr for every class: no register copies at the joins
+    float tmax = fmaxf(fmaxf(s2[0], s2[1]), s2[2]);
+#pragma unroll
+    for (int i = 3; i < 15; i += 2) tmax = fmaxf(fmaxf(tmax, s2[i]), s2[i + 1]);
+    tmax = fmaxf(tmax, s2[15]);
     tmax = half_max(tmax);
     if (__any(tmax > m_run + kRescaleThr)) {                   // deferred rescale, one site
       const float m_new = fmaxf(m_run, tmax);
@@ -229,14 +223,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
 #pragma unroll
       for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
     }
-    if (cls_a) {
-      const float rc = relc - m_run;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rc));
-    } else {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(s2[i] - m_run);
-    }
+    for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(s2[i] - m_run);
     float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) psum += pr[i];

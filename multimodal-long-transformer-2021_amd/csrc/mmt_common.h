@@ -119,4 +119,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (bid & 7) * cpx + (bid >> 3);
 }
 
+// One global_load_lds_dwordx4: lane l's 16 bytes at `gsrc` -> LDS byte address lds_dst + 16 l (M0 = wave-
+// uniform destination, saved and restored).  Issued as asm so that hipcc does not order every later LDS
+// read behind it with a vmcnt(0); completion is counted by hand (vmcnt(0) before the step's barrier).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 }  // namespace mmt
