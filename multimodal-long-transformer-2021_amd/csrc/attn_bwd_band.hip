@@ -455,6 +455,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
 
   for (int it = 0; it < n_it; ++it) {
     const int q0 = w.at(it) * 32;
+    // 4h as a value hipcc must treat as loop-variant: every per-element LDS address below is then
+    // "one base per tile + a literal" -- left to itself the compiler hoisted ~40 lane-dependent addresses
+    // (row * stride, permuted table columns, hash constants) out of the loop, spilled them, and reloaded
+    // them from scratch one by one behind vmcnt(0) waits that also drained the Q/dO prefetch
+    int h4 = 4 * h;
+    asm volatile("" : "+v"(h4));
     tile_to_lds(qlds, qt, lane);
     tile_to_lds(dolds, dot, lane);
     if (it + 1 < n_it) {
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
         c = mma_rows(ef, qf, c);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int id = rb * 32 + kap(i, h);
+          const int id = rb * 32 + (i & 3) + 8 * (i >> 2) + h4;
           tab[r * kTStride(Rp) + tcol(1, m, id)] = fmaf(c[i], p.tscale, bias_ts[id]) + nl;
         }
       }
@@ -502,21 +508,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       frag_from_tile(dof, dolds, lane);
       dp = mma_rows(dof, vf, dp); // dP [q x key]
     }
-    const int dbase = k - q0 - 4 * h;                  // d_i = dbase - ci
+    const int dbase = k - q0 - h4;                     // d_i = dbase - ci
     const float* relrow = rowc + (tc.far_neg ? 64 : 96);   // clipped rel - lse2, per row
 
     float pr[16];
     if (tc.plain && one_id) {                             // class A
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * h;   // q row inside the tile
+        const int row = (i & 3) + 8 * (i >> 2) + h4;      // q row inside the tile
         const float rl = HAS_REL ? relrow[row] : -rowc[row];   // rel - lse2
         pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rl));
       }
     } else if (tc.plain) {                                // class B
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int ci = (i & 3) + 8 * (i >> 2), row = ci + 4 * h;
+        const int ci = (i & 3) + 8 * (i >> 2), row = ci + h4;
         const int lo = tab_addr + row * kTStride(Rp) * 4;
         const int a = med3i(lo + 4 * (m + dbase - ci), lo, lo + 8 * m);
         pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)a));
@@ -525,7 +531,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       const unsigned W2 = 2u * (unsigned)W;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int ci = (i & 3) + 8 * (i >> 2), row = ci + 4 * h;
+        const int ci = (i & 3) + 8 * (i >> 2), row = ci + h4;
         const float rl = HAS_REL ? relrow[row] : -rowc[row];
         const unsigned dd = (unsigned)(dbase - ci + W);
         pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rl) + (dd <= W2 ? 0.f : p.mask_add));
@@ -535,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       const unsigned W2 = 2u * (unsigned)W;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int ci = (i & 3) + 8 * (i >> 2), row = ci + 4 * h;
+        const int ci = (i & 3) + 8 * (i >> 2), row = ci + h4;
         const int qq = q0 + row, d = dbase - ci;
         const bool near = ignore_band | ((unsigned)(d + W) <= W2);
         const bool gq = (unsigned)(qq - p.pat.g0) < (unsigned)p.pat.ng;
@@ -549,17 +555,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
     }
     float g[16];
     if (p.drop_thresh) {
+      // row base of query q0 + ci + 4h = tb + ci * C: one multiply per tile and a literal per element.  tb is
+      // made opaque so that hipcc does not re-associate it into 16 loop-invariant (ci + 4h) * C registers
+      // (it did, and spilled them: 16 scratch reloads per tile inside this loop)
+      const uint32_t tb = bn_seed + (uint32_t)(q0 + h4) * 0x85EBCA6Bu;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int qq = q0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-        const uint32_t bits = drop_bits16(bn_seed + (uint32_t)qq * 0x85EBCA6Bu, (uint32_t)k);
+        const uint32_t bits = drop_bits16(tb + (uint32_t)((i & 3) + 8 * (i >> 2)) * 0x85EBCA6Bu, (uint32_t)k);
         const float df = bits >= p.drop_thresh ? p.inv_keep : 0.f;
-        g[i] = pr[i] * (dp[i] * df - rowc[32 + (i & 3) + 8 * (i >> 2) + 4 * h]);
+        g[i] = pr[i] * (dp[i] * df - rowc[32 + (i & 3) + 8 * (i >> 2) + h4]);
         pr[i] *= df;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) g[i] = pr[i] * (dp[i] - rowc[32 + (i & 3) + 8 * (i >> 2) + 4 * h]);
+      for (int i = 0; i < 16; ++i) g[i] = pr[i] * (dp[i] - rowc[32 + (i & 3) + 8 * (i >> 2) + h4]);
     }
     mma_xt(dv0, dv1, VTile<T>{}, dolds, pr, lane);   // dV^T[d x key] += dO^T[d x q] . P[q x key]
     mma_xt(dk0, dk1, VTile<T>{}, qlds, g, lane);     // dK^T[d x key] += Q^T[d x q] . dS[q x key]
