@@ -142,7 +142,14 @@ class GradientBucketReducer:
     gi = self._bucket_of[p]
     self._pending[gi] -= 1
     if self._pending[gi] == 0:
-      self._handles.append(dist.all_reduce(self.buckets[gi], op=dist.ReduceOp.SUM, async_op=True))
+      self._launch(gi)
+
+  def _launch(self, gi):
+    # weight gradients may still be in flight on fused's side stream: the collective is ordered against
+    # the current stream, so that one has to wait for them first
+    from . import fused
+    fused.wait_side_streams()
+    self._handles.append(dist.all_reduce(self.buckets[gi], op=dist.ReduceOp.SUM, async_op=True))
 
   def finish(self):
     """Waits for the outstanding all-reduces and applies the mean (if requested)."""
@@ -150,7 +157,7 @@ class GradientBucketReducer:
       for gi, left in enumerate(self._pending):     # parameters that received no gradient
         assert left >= 0, 'gradient-ready accounting went negative'
         if left > 0:
-          self._handles.append(dist.all_reduce(self.buckets[gi], op=dist.ReduceOp.SUM, async_op=True))
+          self._launch(gi)
       for h in self._handles:
         h.wait()
       if self.reduce == 'mean':

@@ -8,6 +8,7 @@ and their gradients come back fp32 straight from the kernels.
 from __future__ import annotations
 
 import itertools
+import os
 
 from typing import Optional
 
@@ -255,6 +256,72 @@ def wgrad_accumulate_(dw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, dbias
     _lib.check(L.mmt_wgrad_bias_accumulate(dw.data_ptr(), dw.stride(0), None if dbias is None else dbias.data_ptr(),
                                            dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), M, N, K,
                                            ws.data_ptr(), ws.numel(), _stream(dw)))
+  return True
+
+
+# ---- weight gradients on a side stream -------------------------------------------------------------
+# The weight-gradient GEMMs are off the critical path of backward (nothing but the optimizer reads dW),
+# while the main stream keeps hitting kernels that cannot fill the chip (global-row / global-key combines,
+# fixed-order reduces: ~100 us per layer at a few hundred waves).  Running every dW GEMM on one side
+# stream lets the hardware fill those holes with GEMM workgroups.  Ordering: the side stream waits for the
+# main stream at the point the GEMM is enqueued (dy and x are final), the main stream waits for the side
+# stream when the backward pass ends (engine callback), and the caching allocator is told about the extra
+# stream (record_stream).  A data-parallel reducer calls `wait_side_streams()` right before it launches a
+# bucket's all-reduce (the collective is ordered against the current stream only).
+# MMT_WGRAD_SIDE_STREAM: 0 = never, 1 (default) = single-process runs only, 2 = also under a data-parallel
+# reducer.  The 2-rank rehearsal on one GPU over gloo is correct with it but ~25x slower per step (gloo's
+# CUDA staging path against a second stream), and RCCL cannot be rehearsed on the one-GPU box, so the
+# multi-GPU default stays on the single-stream path.
+_SIDE_MODE = int(os.environ.get('MMT_WGRAD_SIDE_STREAM', '1'))
+WGRAD_SIDE_STREAM = _SIDE_MODE != 0
+_SIDE = {}
+_side_pending = set()
+
+
+def _side_stream(device):
+  s = _SIDE.get(device)
+  if s is None:
+    s = _SIDE[device] = torch.cuda.Stream(device=device)
+  return s
+
+
+def wait_side_streams():
+  """The current stream waits for everything enqueued on the weight-gradient stream(s) so far."""
+  for device in _side_pending:
+    torch.cuda.current_stream(device).wait_stream(_SIDE[device])
+
+
+def _join_side_streams():
+  """Engine callback at the end of backward: the current stream waits for the weight-gradient stream."""
+  for device in list(_side_pending):
+    torch.cuda.current_stream(device).wait_stream(_SIDE[device])
+  _side_pending.clear()
+
+
+def side_stream_ok(*params) -> bool:
+  """Side stream for these parameters' gradients?  Not under a data-parallel reducer unless forced."""
+  if not WGRAD_SIDE_STREAM:
+    return False
+  if _SIDE_MODE >= 2:
+    return True
+  return not any(getattr(p, '_mmt_grad_ready_hooks', ()) for p in params if p is not None)
+
+
+def wgrad_accumulate_side_(dw, dy, x, dbias=None) -> bool:
+  """`wgrad_accumulate_` enqueued on the side stream (inside a backward pass only)."""
+  device = dw.device
+  side = _side_stream(device)
+  main = torch.cuda.current_stream(device)
+  side.wait_stream(main)
+  with torch.cuda.stream(side):
+    ok = wgrad_accumulate_(dw, dy, x, dbias)
+  if not ok:
+    return False
+  for t in (dy, x):
+    t.record_stream(side)
+  if device not in _side_pending:
+    _side_pending.add(device)
+    torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
   return True
 
 

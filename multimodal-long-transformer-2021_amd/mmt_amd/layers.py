@@ -111,8 +111,8 @@ class _LinearFn(torch.autograd.Function):
       if weight.grad is None:
         weight.grad = torch.zeros_like(weight, dtype=torch.float32)
       fuse_b = want_b and bias.grad is not None and bias.grad.dtype == torch.float32 and bias.grad.is_contiguous()
-      if weight.grad.dtype == torch.float32 and fused.wgrad_accumulate_(weight.grad, dy2, x2,
-                                                                         bias.grad if fuse_b else None):
+      wgrad = fused.wgrad_accumulate_side_ if fused.side_stream_ok(weight, bias) else fused.wgrad_accumulate_
+      if weight.grad.dtype == torch.float32 and wgrad(weight.grad, dy2, x2, bias.grad if fuse_b else None):
         b_done = fuse_b
       elif weight.grad.dtype == torch.float32:
         fused.accumulate_grad_(weight.grad, torch.mm(dy2.t(), x2))
