@@ -23,9 +23,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
-  unsigned char* wl = smem + wave * WaveLds<T, Rp>::kBytes;
+  constexpr int kWaveBytes = WaveLds<T, Rp>::kBytes + 4096;      // T table, V tile, K tile
+  unsigned char* wl = smem + wave * kWaveBytes;
   float* tab = reinterpret_cast<float*>(wl);
   unsigned char* vlds = wl + WaveLds<T, Rp>::kTBytesAligned;
+  unsigned char* klds = vlds + 4096;
 
   // ---- work item ------------------------------------------------------------------------
   const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
@@ -63,7 +65,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
   const auto rk = make_rsrc(Kb, (unsigned)(p.S - 1) * ks1b + 128);
   const auto rv = make_rsrc(Vb, (unsigned)(p.S - 1) * vs1b + 128);
   const unsigned voff_q = (unsigned)r * qs1b + 64 * h;
-  const unsigned voff_k = (unsigned)r * ks1b + 64 * h;
+  // K tiles are loaded coalesced (8 rows x 128 B per instruction) and their row fragments read back from a
+  // wave-private LDS tile: a fragment-shaped global load touches every 128-byte line of the tile four times
+  const unsigned voff_k = (unsigned)(lane >> 3) * ks1b + (lane & 7) * 16;
   const unsigned voff_v = (unsigned)(lane >> 3) * vs1b + (lane & 7) * 16;
 
   // ---- tile walk --------------------------------------------------------------------------
@@ -87,14 +91,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
     return it < lenA ? a0 + it : (it < lenA + lenB ? b0 + (it - lenA) : c0 + (it - lenA - lenB));
   };
 
-  Frag<T> qf, kf;
-  bf16x8 vt[4];
+  Frag<T> qf;
+  bf16x8 kt[4], vt[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf.v[s] = buf16(rq, voff_q + 16 * s, (unsigned)q0 * qs1b);
   {
     const unsigned k0 = (unsigned)tile_at(0) * 32;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kf.v[s] = buf16(rk, voff_k + 16 * s, k0 * ks1b);
+    for (int u = 0; u < 4; ++u) kt[u] = buf16(rk, voff_k, (k0 + 8 * u) * ks1b);
 #pragma unroll
     for (int u = 0; u < 4; ++u) vt[u] = buf16(rv, voff_v, (k0 + 8 * u) * vs1b);
   }
@@ -148,14 +152,20 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int ci = lane + 64 * u, row = ci >> 3, ch = ci & 7;
-      *reinterpret_cast<bf16x8*>(vlds + row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16) = vt[u];
+      const int off = row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
+      *reinterpret_cast<bf16x8*>(vlds + off) = vt[u];
+      *reinterpret_cast<bf16x8*>(klds + off) = kt[u];
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    Frag<T> kf;
+    frag_from_tile(kf, klds, lane);
     f32x16 c = {0};
     c = mma_rows(kf, qf, c);     // S^T [key x q]
     if (it + 1 < n_it) {         // prefetch the next tile under this tile's math
       const unsigned k1 = (unsigned)tile_at(it + 1) * 32;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) kf.v[s] = buf16(rk, voff_k + 16 * s, k1 * ks1b);
+      for (int u = 0; u < 4; ++u) kt[u] = buf16(rk, voff_k, (k1 + 8 * u) * ks1b);
 #pragma unroll
       for (int u = 0; u < 4; ++u) vt[u] = buf16(rv, voff_v, (k1 + 8 * u) * vs1b);
     }
@@ -279,11 +289,11 @@ hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st) {
   dim3 grid(p.n_band_blocks + per_bn * p.B * p.N);
   const bool has_rel = p.pat.id_mode == 1 && p.R > 0;
   if (p.R <= 32) {
-    const int lds = 4 * WaveLds<__bf16, 32>::kBytes;
+    const int lds = 4 * (WaveLds<__bf16, 32>::kBytes + 4096);
     if (has_rel) hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, true>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, false>), grid, dim3(256), lds, st, p);
   } else {
-    const int lds = 4 * WaveLds<__bf16, 64>::kBytes;
+    const int lds = 4 * (WaveLds<__bf16, 64>::kBytes + 4096);
     if (has_rel) hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, true>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, false>), grid, dim3(256), lds, st, p);
   }
