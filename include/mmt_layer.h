@@ -163,6 +163,20 @@ int mmt_embed_bwd(const mmt_embed_desc* desc, const void* dout, const int32_t* s
                   const float* rstd, float* dword_table, float* dgamma, float* dbeta, void* dpatch,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-row softmax cross-entropy of wide logits (the tied 30522-way MLM head):
+ *   loss[row] = logsumexp(logits[row, :]) - logits[row, labels[row]]       (natural log; lse saved)
+ * = the `unweighted` term of src/modeling/losses/weighted_sparse_categorical_crossentropy_loss.py:17-43;
+ * the weighting and divide_no_nan reduction over a few hundred rows stay with the caller.
+ * logits are read once in their storage dtype (MMT_F32 | MMT_BF16), row stride `ld` elements.
+ * A label outside [0, C) means "no target": loss 0, zero gradient.
+ * Backward: dlogits[row, i] = (softmax(logits[row])[i] - [i == label]) * coef[row], written in `dtype`. */
+int mmt_xent_fwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld,
+                 const int32_t* labels, float* loss, float* lse, void* stream);
+int mmt_xent_bwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld,
+                 const int32_t* labels, const float* lse, const float* coef, void* dlogits, int64_t ldd,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

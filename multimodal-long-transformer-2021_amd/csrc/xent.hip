@@ -1,0 +1,114 @@
+// Softmax cross-entropy over wide rows (the 30522-way MLM logits): the per-row
+// loss -log softmax(logits)[label] of `weighted_sparse_categorical_crossentropy_loss`
+// (src/modeling/losses/weighted_sparse_categorical_crossentropy_loss.py:17-43) and its gradient, each
+// in ONE pass over the logits in their storage dtype -- TF / torch run cast, max, exp-sum, log, gather
+// and the backward's softmax as separate fp32 passes.  One workgroup per row, online (max, sum) per
+// thread, one LDS combine.  C ABI: include/mmt_layer.h (mmt_xent_fwd / mmt_xent_bwd).
+#include "../../include/mmt_attn.h"
+#include "../../include/mmt_layer.h"
+
+#include "layer_common.h"
+#include "mmt_err.h"
+
+namespace mmt {
+
+template <typename T> __device__ __forceinline__ float ldval(const T* p, long i) { return (float)p[i]; }
+
+struct OnlineLse {
+  float m = -INFINITY, s = 0.f;
+  __device__ __forceinline__ void add(float x) {
+    if (x > m) { s = s * __expf(m - x) + 1.f; m = x; }
+    else s += __expf(x - m);
+  }
+  __device__ __forceinline__ void merge(float m2, float s2) {
+    const float mm = fmaxf(m, m2);
+    if (mm == -INFINITY) return;
+    s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
+    m = mm;
+  }
+};
+
+// rows x C logits (row stride ld elements) -> loss[row] = lse - logits[label], lse[row] (natural log)
+template <typename T>
+__global__ __launch_bounds__(256) void xent_fwd_kernel(const T* logits, long ld, int C, const int* labels,
+                                                       float* loss, float* lse_out) {
+  __shared__ float rm[4], rs[4];
+  const long row = blockIdx.x;
+  const T* x = logits + row * ld;
+  OnlineLse acc;
+  const bool pairs = sizeof(T) == 2 && ((ld & 1) == 0) && ((reinterpret_cast<uintptr_t>(logits) & 3) == 0);
+  if (pairs) {                                    // two bf16 per 4-byte load
+    const int np = C >> 1;
+    const uint32_t* xp = reinterpret_cast<const uint32_t*>(x);
+    for (int i = threadIdx.x; i < np; i += 256) {
+      const uint32_t w = xp[i];
+      acc.add(__uint_as_float(w << 16));
+      acc.add(__uint_as_float(w & 0xFFFF0000u));
+    }
+    if ((C & 1) && threadIdx.x == 0) acc.add(ldval(x, C - 1));
+  } else {
+    for (int i = threadIdx.x; i < C; i += 256) acc.add(ldval(x, i));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc.merge(__shfl_xor(acc.m, o, 64), __shfl_xor(acc.s, o, 64));
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { rm[wave] = acc.m; rs[wave] = acc.s; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    OnlineLse t;
+    for (int w = 0; w < 4; ++w) t.merge(rm[w], rs[w]);
+    const float lse = t.m + logf(t.s);
+    const int lab = labels[row];
+    lse_out[row] = lse;
+    loss[row] = ((unsigned)lab < (unsigned)C) ? lse - ldval(x, lab) : 0.f;   // label outside [0, C): no target
+  }
+}
+
+// dlogits[row][i] = (exp(logits - lse) - [i == label]) * coef[row]
+template <typename T>
+__global__ __launch_bounds__(256) void xent_bwd_kernel(const T* logits, long ld, int C, const int* labels,
+                                                       const float* lse, const float* coef, T* dlogits, long ldd) {
+  const long row = blockIdx.y;
+  const T* x = logits + row * ld;
+  T* dx = dlogits + row * ldd;
+  const int lab = labels[row];
+  const bool has = (unsigned)lab < (unsigned)C;
+  const float l = lse[row], c = has ? coef[row] : 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < C; i += gridDim.x * 256) {
+    const float p = __expf(ldval(x, i) - l);
+    dx[i] = (T)((p - (i == lab ? 1.f : 0.f)) * c);
+  }
+}
+
+}  // namespace mmt
+
+extern "C" {
+
+int mmt_xent_fwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld, const int32_t* labels,
+                 float* loss, float* lse, void* stream) {
+  if (!logits || !labels || !loss || !lse) return mmt::fail(MMT_E_INVALID, "mmt_xent_fwd: NULL argument");
+  if (rows <= 0 || C <= 0 || ld < C) return mmt::fail(MMT_E_INVALID, "mmt_xent_fwd: bad shape");
+  if (dtype != MMT_F32 && dtype != MMT_BF16) return mmt::fail(MMT_E_INVALID, "mmt_xent_fwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMT_BF16) hipLaunchKernelGGL(mmt::xent_fwd_kernel<__bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const __bf16*)logits, (long)ld, C, labels, loss, lse);
+  else hipLaunchKernelGGL(mmt::xent_fwd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, (long)ld, C, labels, loss, lse);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_xent_fwd: %s", hipGetErrorString(e));
+}
+
+int mmt_xent_bwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld, const int32_t* labels,
+                 const float* lse, const float* coef, void* dlogits, int64_t ldd, void* stream) {
+  if (!logits || !labels || !lse || !coef || !dlogits) return mmt::fail(MMT_E_INVALID, "mmt_xent_bwd: NULL argument");
+  if (rows <= 0 || rows > 65535 || C <= 0 || ld < C || ldd < C) return mmt::fail(MMT_E_INVALID, "mmt_xent_bwd: bad shape");
+  if (dtype != MMT_F32 && dtype != MMT_BF16) return mmt::fail(MMT_E_INVALID, "mmt_xent_bwd: bad dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  int bx = (C + 256 * 8 - 1) / (256 * 8);
+  bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+  dim3 grid(bx, (unsigned)rows);
+  if (dtype == MMT_BF16) hipLaunchKernelGGL(mmt::xent_bwd_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)logits, (long)ld, C, labels, lse, coef, (__bf16*)dlogits, (long)ldd);
+  else hipLaunchKernelGGL(mmt::xent_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, (long)ld, C, labels, lse, coef, (float*)dlogits, (long)ldd);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_xent_bwd: %s", hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -449,3 +449,41 @@ def embed_assemble(word_ids, seg_ids, word_table, seg_table, gamma, beta, pos_ta
   [B, n_patch, H] (projection bias included) is added at positions [patch_start, patch_start+n_patch)."""
   return _EmbedAssembleFn.apply(word_ids, seg_ids, word_table, seg_table, pos_table, gamma, beta, patch_proj,
                                 (eps, p, seed, patch_start, out_dtype))
+
+
+# ---- softmax cross-entropy over wide rows (MLM / MPP heads) ---------------------------------------
+class _SoftmaxXentFn(torch.autograd.Function):
+  """loss[row] = logsumexp(logits[row]) - logits[row, label[row]] (fp32), one pass over the logits in
+  their storage dtype; backward writes dlogits = (softmax - onehot) * dloss[row] in that dtype."""
+
+  @staticmethod
+  def forward(ctx, logits, labels):
+    _check(logits, labels)
+    rows, C = logits.shape
+    lab = labels.reshape(-1).to(torch.int32).contiguous()
+    loss = torch.empty(rows, dtype=torch.float32, device=logits.device)
+    lse = torch.empty_like(loss)
+    with torch.cuda.device(logits.device):
+      _lib.check(_lib.lib().mmt_xent_fwd(rows, C, _dtype_code(logits.dtype), _p(logits), logits.stride(0), _p(lab),
+                                         _p(loss), _p(lse), _stream(logits)))
+    ctx.save_for_backward(logits, lab, lse)
+    return loss
+
+  @staticmethod
+  def backward(ctx, dloss):
+    logits, lab, lse = ctx.saved_tensors
+    rows, C = logits.shape
+    coef = dloss.to(torch.float32).contiguous()
+    dlogits = torch.empty_like(logits)
+    with torch.cuda.device(logits.device):
+      _lib.check(_lib.lib().mmt_xent_bwd(rows, C, _dtype_code(logits.dtype), _p(logits), logits.stride(0), _p(lab),
+                                         _p(lse), _p(coef), _p(dlogits), dlogits.stride(0), _stream(logits)))
+    return dlogits, None
+
+
+def softmax_cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+  """Per-row -log softmax(logits)[label] (fp32 [rows]) for 2-D logits (fp32 | bf16, unit column stride,
+  at most 65535 rows); labels outside [0, C) give loss 0 and no gradient."""
+  if logits.dim() != 2 or logits.stride(1) != 1 or logits.shape[0] > 65535:
+    raise ValueError('softmax_cross_entropy expects [rows <= 65535, C] logits with unit column stride')
+  return _SoftmaxXentFn.apply(logits, labels)

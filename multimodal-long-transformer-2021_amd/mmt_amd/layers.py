@@ -484,8 +484,13 @@ def weighted_sparse_categorical_crossentropy_loss(logits, labels, label_weights,
                                                   name='', pos_weights=None):
   """`src/modeling/losses/weighted_sparse_categorical_crossentropy_loss.py:17-43` incl.
   `divide_no_nan` (an all-zero weight vector gives loss 0, App. B q13)."""
-  flat = logits.float().reshape(-1, logits.shape[-1])
-  unweighted = F.cross_entropy(flat, labels.reshape(-1).long(), reduction='none').view(labels.shape)
+  flat = logits.reshape(-1, logits.shape[-1])
+  if (flat.is_cuda and flat.dtype in (torch.float32, torch.bfloat16) and flat.stride(1) == 1
+      and 0 < flat.shape[0] <= 65535 and flat.shape[1] >= 64):
+    # wide rows (30522-way MLM, 512-way MPP): one HIP pass over the logits in their storage dtype
+    unweighted = fused.softmax_cross_entropy(flat, labels.reshape(-1)).view(labels.shape)
+  else:
+    unweighted = F.cross_entropy(flat.float(), labels.reshape(-1).long(), reduction='none').view(labels.shape)
   if pos_weights is not None:
     unweighted = unweighted * pos_weights.to(unweighted.dtype)
   w = label_weights.to(unweighted.dtype)

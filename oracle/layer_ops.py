@@ -129,3 +129,20 @@ def embed_assemble_bwd(dout, word_ids, seg_ids, word_table, seg_table, gamma, n_
   if has_pos:
     res['pos'] = dout.sum(0)
   return res
+
+
+# ---- per-row softmax cross-entropy (weighted_sparse_categorical_crossentropy_loss.py:17-43) --------
+def softmax_xent(logits, labels):
+  """loss[row] = logsumexp(logits[row]) - logits[row, label]; labels outside [0, C) -> 0 (no target).
+  Returns (loss, dlogits_per_unit_coef) with dlogits = softmax - onehot (zero rows for no-target)."""
+  x = logits.astype(np.float64)
+  m = x.max(-1, keepdims=True)
+  lse = m[:, 0] + np.log(np.exp(x - m).sum(-1))
+  C = x.shape[1]
+  ok = (labels >= 0) & (labels < C)
+  lab = np.clip(labels, 0, C - 1)
+  loss = np.where(ok, lse - x[np.arange(x.shape[0]), lab], 0.0)
+  d = np.exp(x - lse[:, None])
+  d[np.arange(x.shape[0]), lab] -= 1.0
+  d[~ok] = 0.0
+  return loss, d
