@@ -10,7 +10,7 @@ from . import configs, distribute, optimization, tasks
 
 def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.bfloat16):
   exp = configs.get_exp_config('mmt/pretraining')
-  P = 63
+  P = cfg.get('P', 63)          # patches per image row (image side 16 P)
   exp.override({
       'task': {
           'micro_batch_size': cfg['B'],
