@@ -477,7 +477,11 @@ class ClassificationHead(nn.Module):
 
   @property
   def checkpoint_items(self):
-    return {'dense': self.dense_weight, 'out_proj': self.out_proj_weight}
+    # TFM ClassificationHead.checkpoint_items: the inner dense layer and the output projection
+    items = {'out_proj': {'kernel': self.out_proj_weight, 'bias': self.out_proj_bias}}
+    if self.dense_weight is not None:
+      items['dense'] = {'kernel': self.dense_weight, 'bias': self.dense_bias}
+    return items
 
 
 def weighted_sparse_categorical_crossentropy_loss(logits, labels, label_weights, metrics=None,

@@ -63,6 +63,26 @@ class FusedAdamW:
   def zero_grad(self, set_to_none: bool = False):
     self.reducer.zero_grad()
 
+  def state_dict(self):
+    """Step count, learning rate and the flat moment slabs (the parameters themselves are model state)."""
+    return {'t': self.t, 'lr': self.param_groups[0]['lr'],
+            'slabs': [{'m': s['m'].detach().cpu(), 'v': s['v'].detach().cpu()} for s in self.slabs]}
+
+  def load_state_dict(self, state):
+    if len(state['slabs']) != len(self.slabs) or any(a['m'].numel() != b['m'].numel() for a, b in zip(state['slabs'], self.slabs)):
+      raise ValueError('optimizer state does not match this model / bucket layout')
+    self.t = int(state['t'])
+    self.param_groups[0]['lr'] = float(state['lr'])
+    for src, dst in zip(state['slabs'], self.slabs):
+      dst['m'].copy_(src['m']); dst['v'].copy_(src['v'])
+    self.refresh_shadow()
+
+  def refresh_shadow(self):
+    """Re-derive the bf16 shadow weights after the master parameters were written from outside
+    (checkpoint restore, manual initialisation)."""
+    for slab in self.slabs:
+      slab['shadow'].copy_(slab['param'])
+
   @torch.no_grad()
   def step(self, grad_scale=None):
     self.t += 1

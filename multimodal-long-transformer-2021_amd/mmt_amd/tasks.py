@@ -110,6 +110,15 @@ class _TaskBase:
     return {self.loss: all_loss}
 
   @torch.no_grad()
+  def initialize(self, model):
+    """`pretraining.py:341-351`: load `task_config.init_checkpoint` (file, or the latest checkpoint of a
+    directory) into the whole model by checkpoint-item name; missing items are tolerated."""
+    from . import checkpoint
+    path = checkpoint.latest_checkpoint(getattr(self.task_config, 'init_checkpoint', '') or '')
+    if not path:
+      return []                        # 'init_checkpoint is empty. Train from scratch.'
+    return checkpoint.restore_items(path, checkpoint.model_items(model))
+
   def validation_step(self, inputs, model, metrics=None):
     inputs, labels = inputs
     outputs = model(**inputs, training=False)
@@ -173,6 +182,23 @@ class ClassificationTask(_TaskBase):
     hidden = config.encoder.get().hidden_size
     heads = [layers.ClassificationHead(hidden, **c.as_dict()) for c in config.cls_heads]
     return models.MmtClassificationModel(encoder=encoder, classification_heads=heads)
+
+  def initialize(self, model):
+    """`classification.py:229-253`: from `init_checkpoint` restore the encoder, plus every checkpoint item
+    of the fine-tuning model whose key contains the name of one of its classification heads (the
+    reference's own matching rule; with its `checkpoint_items` that is the encoder only unless a key
+    carries the head's name)."""
+    from . import checkpoint
+    path = checkpoint.latest_checkpoint(self.task_config.init_checkpoint or '')
+    if not path:
+      return []
+    items = checkpoint.model_items(model)
+    mapping = {'encoder': items['encoder']}
+    for head_cfg in self.task_config.model.cls_heads:
+      for key, item in items.items():
+        if head_cfg.name and head_cfg.name in key:
+          mapping[key] = item
+    return checkpoint.restore_items(path, mapping)
 
   def build_losses(self, labels, model_outputs, metrics=None, aux_losses=None):
     """`classification.py:100-126` (the num_classes == 1 branch is dead in the reference, q6)."""

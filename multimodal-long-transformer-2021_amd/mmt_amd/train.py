@@ -13,7 +13,7 @@ import time
 
 import torch
 
-from . import configs, distribute, optimization, tasks
+from . import checkpoint, configs, distribute, optimization, tasks
 
 
 def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, device=None,
@@ -31,6 +31,7 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
                         num_replicas=strategy.num_replicas_in_sync)
   torch.manual_seed(0)     # identical initial weights on every replica
   model = task.build_model().to(device)
+  task.initialize(model)              # warm start from task.init_checkpoint (no-op when empty)
   opt_cfg = params.trainer.optimizer_config
   reducer = strategy.make_reducer(list(model.parameters()),
                                   reduce='sum' if not params.task.scale_loss and os.environ.get('MMT_REFERENCE_SUM') else 'mean')
@@ -38,9 +39,23 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
   data = task.build_inputs(params.task.train_data, device=device, rank=strategy.rank)
   steps = max_steps or params.trainer.train_steps
   logs = []
+  start = 0
+  resume_from = checkpoint.latest_checkpoint(model_dir) if model_dir and os.path.isdir(model_dir) else None
+  if resume_from:                       # restart: model, optimizer moments and step from the latest checkpoint
+    start = checkpoint.restore(resume_from, model, optimizer)
+    if hasattr(optimizer, 'refresh_shadow'):
+      optimizer.refresh_shadow()
+    if strategy.rank == 0:
+      print(json.dumps({'resumed_from': resume_from, 'step': start}), flush=True)
+  ckpt_every = params.trainer.checkpoint_interval
+
+  def save(step):
+    if strategy.rank == 0 and model_dir:
+      checkpoint.save(model_dir, step, model, optimizer, max_to_keep=params.trainer.max_to_keep)
+
   if 'train' in mode:
     t0 = time.perf_counter()
-    for step in range(steps):
+    for step in range(start, steps):
       optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, step))
       out = task.train_step(next(data), model, optimizer, metrics={}, reducer=reducer,
                             clip_norm=opt_cfg.gradient_clip_norm)
@@ -49,9 +64,10 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
         logs.append({'step': step, 'loss': loss, 'elapsed_s': time.perf_counter() - t0})
         if strategy.rank == 0:
           print(json.dumps(logs[-1]), flush=True)
-    if strategy.rank == 0 and model_dir:
-      os.makedirs(model_dir, exist_ok=True)
-      torch.save({'model': model.state_dict(), 'step': steps}, os.path.join(model_dir, 'ckpt.pt'))
+      if ckpt_every and (step + 1) % ckpt_every == 0 and step + 1 < steps:
+        save(step + 1)
+    if steps > start:
+      save(steps)
   if 'eval' in mode:
     vdata = task.build_inputs(params.task.validation_data, device=device, rank=strategy.rank)
     out = task.validation_step(next(vdata), model, metrics={})
