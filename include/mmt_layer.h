@@ -33,7 +33,10 @@ typedef struct mmt_rows_desc {
   uint64_t dropout_seed;
   int32_t accumulate;  /* backward: != 0 adds dbias / dgamma / dbeta INTO the given buffers (fp32
                           master gradients) instead of overwriting them                       */
-  int32_t reserved;
+  int32_t defer_reduce; /* backward: != 0 leaves the column-sum partials in the workspace and does NOT launch
+                           the fixed-order reduce; the caller finishes with mmt_colsum_reduce (same desc,
+                           same workspace) on a stream of its choice -- the parameter gradients are off the
+                           critical path of backward                                                      */
 } mmt_rows_desc;
 
 /* Bytes of scratch the *_bwd entry points need (column-sum partials). */
@@ -62,6 +65,13 @@ int mmt_residual_block_bwd(const mmt_rows_desc* desc, const void* dx_new_in, con
                            const void* x_new, const float* gamma, const float* mean,
                            const float* rstd, void* d_o, void* dx, float* dbias, float* dgamma,
                            float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Second half of a *_bwd call made with desc->defer_reduce: sums the partial column sums the first
+ * half left in `workspace` into (o0, o1, o2) in fixed order (overwrite, or add with desc->accumulate).
+ * kind: 0 = mmt_ln_bwd (dgamma, dbeta), 1 = mmt_residual_block_bwd with LayerNorm (dbias, dgamma, dbeta),
+ * 2 = mmt_residual_block_bwd without LayerNorm (dbias), 3 = mmt_bias_gelu_bwd (dbias). */
+int mmt_colsum_reduce(const mmt_rows_desc* desc, int32_t kind, const void* workspace, float* o0, float* o1,
+                      float* o2, void* stream);
 
 /* y = gelu_tanh(u + bias)   (DenseLayers hidden activation; rows x H with H = intermediate_size) */
 int mmt_bias_gelu_fwd(const mmt_rows_desc* desc, const void* u, const float* bias, void* y,

@@ -456,6 +456,7 @@ int mmt_ln_bwd(const mmt_rows_desc* d, const void* dy, const void* x, const floa
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = launch_bwd<false, true>(p, d->dtype == MMT_BF16, st, p.nblocks);
   if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_ln_bwd: %s", hipGetErrorString(e));
+  if (d->defer_reduce) return MMT_OK;
   hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((2 * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, 2, d->H, dgamma, dbeta, (float*)nullptr, d->accumulate);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_ln_bwd reduce: %s", hipGetErrorString(e));
@@ -493,9 +494,22 @@ int mmt_residual_block_bwd(const mmt_rows_desc* d, const void* dx_new_in, const 
   hipError_t e = has_ln ? launch_bwd<true, true>(p, bf16, st, p.nblocks) : launch_bwd<true, false>(p, bf16, st, p.nblocks);
   if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_residual_block_bwd: %s", hipGetErrorString(e));
   const int ksets = has_ln ? 3 : 1;
+  if (d->defer_reduce) return MMT_OK;
   hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((ksets * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, ksets, d->H, dbias, dgamma, dbeta, d->accumulate);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_residual_block_bwd reduce: %s", hipGetErrorString(e));
+}
+
+int mmt_colsum_reduce(const mmt_rows_desc* d, int32_t kind, const void* ws, float* o0, float* o1, float* o2,
+                      void* stream) {
+  if (int rc = check_rows(d, 8192)) return rc;
+  if (!ws || !o0 || kind < 0 || kind > 3) return lfail(MMT_E_INVALID, "mmt_colsum_reduce: bad argument");
+  int nblocks, ksets;
+  if (kind == 3) { nblocks = (int)(d->rows < kGeluRowSplit ? d->rows : kGeluRowSplit); ksets = 1; }
+  else { nblocks = row_blocks(d); ksets = kind == 0 ? 2 : (kind == 1 ? 3 : 1); }
+  if ((ksets >= 2 && !o1) || (ksets >= 3 && !o2)) return lfail(MMT_E_INVALID, "mmt_colsum_reduce: output missing");
+  hipError_t e = mmt::launch_colsum_reduce((const float*)ws, nblocks, ksets, d->H, o0, o1, o2, d->accumulate, (hipStream_t)stream);
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_colsum_reduce: %s", hipGetErrorString(e));
 }
 
 int mmt_accumulate_grad(float* acc, const void* g, int32_t g_dtype, int64_t n, void* stream) {
@@ -554,6 +568,7 @@ int mmt_bias_gelu_bwd(const mmt_rows_desc* d, const void* dy, const void* u, con
   else hipLaunchKernelGGL((mmt::bias_gelu_kernel<float, true>), grid, dim3(256), 0, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_bias_gelu_bwd: %s", hipGetErrorString(e));
+  if (d->defer_reduce) return MMT_OK;
   hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((d->H + 63) / 64), dim3(1024), 0, st, p.part, (int)gy, 1, d->H, dbias, (float*)nullptr, (float*)nullptr, d->accumulate);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_bias_gelu_bwd reduce: %s", hipGetErrorString(e));

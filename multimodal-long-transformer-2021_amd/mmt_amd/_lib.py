@@ -23,7 +23,7 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
            'mmt_attn_bwd', 'mmt_side_inputs',
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
-           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_accumulate_grad', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
+           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_colsum_reduce', 'mmt_accumulate_grad', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
            'mmt_wgrad_bias_accumulate', 'mmt_wgrad_workspace_bytes', 'mmt_embed_fwd', 'mmt_embed_bwd',
            'mmt_embed_workspace_bytes', 'mmt_xent_fwd', 'mmt_xent_bwd')
 
@@ -39,7 +39,7 @@ class RowsDesc(ctypes.Structure):
   _fields_ = [('rows', ctypes.c_int64), ('H', ctypes.c_int32), ('dtype', ctypes.c_int32),
               ('eps', ctypes.c_float), ('dropout_p', ctypes.c_float),
               ('dropout_seed', ctypes.c_uint64), ('accumulate', ctypes.c_int32),
-              ('reserved', ctypes.c_int32)]
+              ('defer_reduce', ctypes.c_int32)]
 
 
 class MaskDesc(ctypes.Structure):
@@ -125,6 +125,8 @@ def lib() -> ctypes.CDLL:
   L.mmt_ln_bwd.argtypes = [rd] + [vp] * 9 + [ctypes.c_size_t, vp]
   L.mmt_residual_block_bwd.argtypes = [rd] + [vp] * 12 + [ctypes.c_size_t, vp]
   L.mmt_bias_gelu_bwd.argtypes = [rd] + [vp] * 6 + [ctypes.c_size_t, vp]
+  L.mmt_colsum_reduce.restype = ctypes.c_int
+  L.mmt_colsum_reduce.argtypes = [rd, ctypes.c_int32, vp, vp, vp, vp, vp]
   L.mmt_wgrad_accumulate.restype = ctypes.c_int
   L.mmt_wgrad_accumulate.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int32,
                                      ctypes.c_int32, ctypes.c_int64, vp, ctypes.c_size_t, vp]

@@ -111,10 +111,13 @@ class _LayerNormFn(torch.autograd.Function):
       dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
     d = _desc(x2, ctx.eps)
     d.accumulate = int(direct)
+    d.defer_reduce = int(side_stream_ok(gamma_p, beta_p))
     ws = _ws(d, x2)
     with torch.cuda.device(x2.device):
       _lib.check(_lib.lib().mmt_ln_bwd(d, _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg),
                                        _p(db), _p(ws), ws.numel(), _stream(x2)))
+    if d.defer_reduce:
+      _reduce_on_side(d, 0, ws, (dg, db))
     return dx.view(ctx.shape), _finish(gamma_p, dg, direct), _finish(beta_p, db, direct), None
 
 
@@ -171,11 +174,14 @@ class _ResidualBlockFn(torch.autograd.Function):
       db = torch.empty_like(gamma) if has_ln else None
     d = _desc(x_new, eps, p, seed)
     d.accumulate = int(direct)
+    d.defer_reduce = int(side_stream_ok(bias_p, gamma_p, beta_p))
     ws = _ws(d, x_new)
     with torch.cuda.device(x_new.device):
       _lib.check(_lib.lib().mmt_residual_block_bwd(
           d, _p(dxn), _p(dh2), _p(x_new), _p(gamma), _p(mean), _p(rstd), _p(d_o), _p(dx), _p(dbias),
           _p(dg), _p(db), _p(ws), ws.numel(), _stream(x_new)))
+    if d.defer_reduce:
+      _reduce_on_side(d, 1 if has_ln else 2, ws, (dbias, dg, db) if has_ln else (dbias,))
     return (d_o.view(shape), _finish(bias_p, dbias, direct), dx.view(shape),
             _finish(gamma_p, dg, direct) if has_ln else None,
             _finish(beta_p, db, direct) if has_ln else None, None, None, None)
@@ -211,10 +217,13 @@ class _BiasGeluFn(torch.autograd.Function):
     dbias, direct = _grad_target(ctx.param, bias)
     d = _desc(u2)
     d.accumulate = int(direct)
+    d.defer_reduce = int(side_stream_ok(ctx.param))
     ws = _ws(d, u2)
     with torch.cuda.device(u2.device):
       _lib.check(_lib.lib().mmt_bias_gelu_bwd(d, _p(dy2), _p(u2), _p(bias), _p(du), _p(dbias), _p(ws),
                                               ws.numel(), _stream(u2)))
+    if d.defer_reduce:
+      _reduce_on_side(d, 3, ws, (dbias,))
     return du.view(ctx.shape), _finish(ctx.param, dbias, direct)
 
 
@@ -319,10 +328,31 @@ def wgrad_accumulate_side_(dw, dy, x, dbias=None) -> bool:
     return False
   for t in (dy, x):
     t.record_stream(side)
+  _mark_side(device)
+  return True
+
+
+def _mark_side(device):
   if device not in _side_pending:
     _side_pending.add(device)
     torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
-  return True
+
+
+def _reduce_on_side(d, kind, ws, outs, *params):
+  """Second half of a *_bwd call made with d.defer_reduce: the fixed-order column-sum reduce (parameter
+  gradients: nothing on the critical path reads them) goes to the side stream."""
+  device = ws.device
+  side = _side_stream(device)
+  side.wait_stream(torch.cuda.current_stream(device))
+  o = list(outs) + [None] * (3 - len(outs))
+  with torch.cuda.stream(side):
+    with torch.cuda.device(device):
+      _lib.check(_lib.lib().mmt_colsum_reduce(d, kind, _p(ws), _p(o[0]), _p(o[1]), _p(o[2]), side.cuda_stream))
+  ws.record_stream(side)
+  for t in outs:
+    if t is not None:
+      t.record_stream(side)
+  _mark_side(device)
 
 
 _WGRAD_WS = {}
