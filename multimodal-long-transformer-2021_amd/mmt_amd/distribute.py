@@ -85,6 +85,7 @@ class GradientBucketReducer:
     self.buckets: List[torch.Tensor] = []
     self.layout = []            # (param, bucket index, element offset) for flat optimizers
     self.buckets_are_zero = True
+    self.pending_scale = 1.0
     self._bucket_of, self._pending, self._handles = {}, [], []
     self._ready = set()         # parameters already counted in this (armed) backward
     order = list(reversed(self.params))
@@ -151,8 +152,12 @@ class GradientBucketReducer:
     fused.wait_side_streams()
     self._handles.append(dist.all_reduce(self.buckets[gi], op=dist.ReduceOp.SUM, async_op=True))
 
-  def finish(self):
-    """Waits for the outstanding all-reduces and applies the mean (if requested)."""
+  def finish(self, defer_mean: bool = False):
+    """Waits for the outstanding all-reduces and applies the mean (if requested).  With `defer_mean`
+    the buckets keep the SUM over replicas and the 1/world factor is remembered instead
+    (`pending_scale`): `clip_by_global_norm(apply=False)` folds it into the factor a fused optimizer
+    multiplies the gradients with, which saves one read-modify-write pass over every gradient."""
+    self.pending_scale = 1.0
     if self.world > 1:
       for gi, left in enumerate(self._pending):     # parameters that received no gradient
         assert left >= 0, 'gradient-ready accounting went negative'
@@ -161,8 +166,11 @@ class GradientBucketReducer:
       for h in self._handles:
         h.wait()
       if self.reduce == 'mean':
-        for b in self.buckets:
-          b.mul_(1.0 / self.world)
+        if defer_mean:
+          self.pending_scale = 1.0 / self.world
+        else:
+          for b in self.buckets:
+            b.mul_(1.0 / self.world)
     self._handles = []
     self._ready = set()
 
@@ -170,8 +178,15 @@ class GradientBucketReducer:
     """Returns the clip factor min(1, max_norm / ||g||) as a device scalar; with apply=False the
     gradients are left alone (a fused optimizer multiplies them while it reads them)."""
     norms = torch._foreach_norm(self.buckets)                 # one pass, no temporaries
-    total = torch.linalg.vector_norm(torch.stack(norms))
-    scale = torch.clamp(max_norm / (total + 1e-6), max=1.0).float()
+    ps = getattr(self, 'pending_scale', 1.0)                  # buckets hold ps^-1 x the true gradient
+    total = torch.linalg.vector_norm(torch.stack(norms)) * ps
+    scale = torch.clamp(max_norm / (total + 1e-6), max=1.0).float() * ps
     if apply:
       torch._foreach_mul_(self.buckets, scale)
+      self.pending_scale = 1.0
     return scale
+
+  def pending_scale_tensor(self):
+    """The deferred mean factor as a device scalar (for a fused optimizer when no clipping is asked)."""
+    ps = getattr(self, 'pending_scale', 1.0)
+    return None if ps == 1.0 else torch.full((), ps, dtype=torch.float32, device=self.buckets[0].device)

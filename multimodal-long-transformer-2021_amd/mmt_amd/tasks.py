@@ -98,9 +98,12 @@ class _TaskBase:
     fused_opt = hasattr(optimizer, 'slabs')          # optimization.FusedAdamW
     scale = None
     if reducer is not None:
-      reducer.finish()                   # gradient all-reduce == optimizer.apply_gradients(:273)
+      # gradient all-reduce == optimizer.apply_gradients(:273); a fused optimizer applies 1/world itself
+      reducer.finish(defer_mean=fused_opt)
       if clip_norm:
         scale = reducer.clip_by_global_norm(clip_norm, apply=not fused_opt)
+      elif fused_opt:
+        scale = reducer.pending_scale_tensor()
     elif clip_norm:
       torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
     if fused_opt:

@@ -69,3 +69,52 @@ def test_two_ranks_on_one_gpu_average_their_bucket_gradients():
   # so the two reducers' concatenated buckets line up element for element
   assert l0.numel() == r0.numel() and float(r0.abs().max()) > 0
   assert torch.allclose(r0.double(), (l0.double() + l1.double()) / 2, atol=1e-6, rtol=1e-5)
+
+
+def _step_worker(rank, world, port, out):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                    HSA_ENABLE_IPC_MODE_LEGACY='0')
+  import torch.distributed as dist
+  import mmt_amd
+  from mmt_amd import distribute, optimization
+  dist.init_process_group('gloo')
+  torch.cuda.set_device(0)
+  exp = tiny_experiment(S=256, radius=32, n_global=8)
+  exp.task.model.encoder.mmt.hidden_dropout_prob = 0.0
+  exp.task.model.encoder.mmt.attention_probs_dropout_prob = 0.0
+
+  def make(num_replicas, strategy):
+    task = mmt_amd.tasks.get_task(exp.task, compute_dtype=torch.bfloat16, num_replicas=num_replicas)
+    torch.manual_seed(6)
+    model = task.build_model().cuda()
+    reducer = strategy.make_reducer(list(model.parameters()), reduce='mean')
+    opt = optimization.create_optimizer(model, exp.trainer.optimizer_config, reducer=reducer)
+    optimization.set_learning_rate(opt, 1e-3)
+    return task, model, reducer, opt
+
+  batches = [next(mmt_amd.tasks.get_task(exp.task, compute_dtype=torch.bfloat16).build_inputs(
+      exp.task.train_data, device='cuda', rank=r, batch_size=2)) for r in range(world)]
+  # data-parallel step: this rank's half, mean folded into the fused optimizer's gradient scale
+  task, model, reducer, opt = make(world, distribute.DataParallelStrategy('gloo', bucket_mb=0.25))
+  task.train_step(batches[rank], model, opt, reducer=reducer, clip_norm=1.0, micro_batch_size=2)
+  # reference: one process, both halves as two micro-batches
+  cat = lambda vs: torch.cat(vs, 0) if torch.is_tensor(vs[0]) else vs[0]
+  both = tuple({k: cat([b[i][k] for b in batches]) for k in batches[0][i]} for i in (0, 1))
+  task1, model1, reducer1, opt1 = make(1, distribute.DataParallelStrategy(None))
+  task1.train_step(both, model1, opt1, reducer=reducer1, clip_norm=1.0, micro_batch_size=2)
+  worst = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(model.parameters(), model1.parameters()))
+  moved = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(model1.parameters(), make(1, distribute.DataParallelStrategy(None))[1].parameters()))
+  out[rank] = (worst, moved, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+  dist.destroy_process_group()
+
+
+def test_data_parallel_train_step_equals_micro_batched_single_process():
+  """Two ranks x 2 samples with the deferred 1/world mean == one process x 2 micro-batches of 2."""
+  world = 2
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_step_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+  (w0, m0, p0), (w1, m1, p1) = out[0], out[1]
+  assert torch.equal(p0, p1)                      # replicas stay in sync
+  assert m0 > 1e-4                                 # the step moved the parameters ...
+  assert max(w0, w1) < 1e-6 + 1e-3 * m0            # ... to the same place as the single-process reference
