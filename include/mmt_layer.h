@@ -116,6 +116,10 @@ int mmt_adamw_step(const mmt_adamw_desc* desc, float* param, float* grad, float*
  * written as plain fp32 slabs and summed in fixed order (bitwise reproducible); without one they
  * are added with float atomics (order not fixed). */
 size_t mmt_wgrad_workspace_bytes(int32_t M, int32_t N, int64_t K);
+/* Compute units one weight-gradient GEMM may fill (default 256 = the whole MI355X, clamped to [32, 256]).
+ * Process-wide; a data-parallel host lowers it so that the split-K grid and the collective kernels
+ * overlapping backward fit the chip together.  Affects mmt_wgrad_workspace_bytes: query after setting. */
+void mmt_wgrad_set_cu_budget(int32_t cus);
 int mmt_wgrad_accumulate(float* dw, int64_t ldw, const void* dy, int64_t ldy, const void* x,
                          int64_t ldx, int32_t M, int32_t N, int64_t K, void* workspace,
                          size_t workspace_bytes, void* stream);

@@ -18,6 +18,7 @@
 #include "attn_tile.h"
 #include "mmt_err.h"
 
+#include <atomic>
 #include <cstdlib>
 
 namespace mmt {
@@ -396,16 +397,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* dw, long ldw, 
 }  // namespace mmt
 
 namespace {
+// Compute units the GEMM may fill with one round of workgroups (mmt_wgrad_set_cu_budget): 256 on a GPU of
+// its own; a data-parallel run leaves some to the collective kernels that overlap backward -- the 256-row
+// kernels hold a whole CU per workgroup, so a full-chip grid next to RCCL's resident workgroups would need
+// a second, nearly empty round.
+std::atomic<int> g_cu_budget{256};
 // 256-row tiles (8 waves, one workgroup per CU) when M allows, else 128-row tiles (4 waves, 2 per CU)
 int wgrad_tile_m(int M) { return (M % 256) == 0 ? 256 : 128; }
 // split-K factor: one full round of workgroups, slices of >= 256 rows
 int wgrad_split(int tiles, long K, int tile_m) {
-  int split = (tile_m == 256 ? 256 : 512) / tiles;
+  const int cus = g_cu_budget.load(std::memory_order_relaxed);
+  int split = (tile_m == 256 ? cus : 2 * cus) / tiles;
   const int max_split = (int)((K + 255) / 256);
   if (split > max_split) split = max_split;
   return split < 1 ? 1 : split;
 }
 }  // namespace
+
+extern "C" void mmt_wgrad_set_cu_budget(int32_t cus) {
+  g_cu_budget.store(cus < 32 ? 32 : (cus > 256 ? 256 : cus), std::memory_order_relaxed);
+}
 
 extern "C" size_t mmt_wgrad_workspace_bytes(int32_t M, int32_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0 || (M % 128) || (N % mmt::kWgTN)) return 0;

@@ -112,6 +112,10 @@ class GradientBucketReducer:
     self._group_sizes = list(self._pending)
     self.armed = True
     if self.world > 1:
+      if self.params and self.params[0].is_cuda:
+        # leave compute units to the RCCL kernels that run under backward (csrc/wgrad_gemm.hip)
+        from . import _lib
+        _lib.lib().mmt_wgrad_set_cu_budget(int(os.environ.get('MMT_WGRAD_CUS', '224')))
       for p in self.params:
         p.register_post_accumulate_grad_hook(self._on_grad_ready)
         # Kernels that add a gradient straight into `.grad` (weight-gradient GEMM, fused-layer column

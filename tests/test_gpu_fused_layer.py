@@ -246,3 +246,25 @@ def test_weighted_loss_uses_fused_xent_and_matches_torch():
   assert float((logits.grad.float() - ref_logits.grad).abs().max()) < 2.0 ** -8 * float(ref_logits.grad.abs().max()) + 1e-7
   zero = layers.weighted_sparse_categorical_crossentropy_loss(logits, labels, torch.zeros_like(w))
   assert float(zero) == 0.0                                  # divide_no_nan
+
+
+def test_wgrad_cu_budget_changes_the_split_not_the_result():
+  """mmt_wgrad_set_cu_budget (data-parallel runs leave CUs to the collectives): same dW, other grid."""
+  from mmt_amd import _lib, fused
+  L = _lib.lib()
+  torch.manual_seed(0)
+  K, M, N = 8192, 768, 768        # split-K not capped by the slice length: 28 / 24 / 7 slabs
+  dy = torch.randn(K, M, device='cuda').to(torch.bfloat16)
+  x = torch.randn(K, N, device='cuda').to(torch.bfloat16)
+  want = dy.double().t() @ x.double()
+  sizes = []
+  try:
+    for cus in (256, 224, 64):
+      L.mmt_wgrad_set_cu_budget(cus)
+      sizes.append(L.mmt_wgrad_workspace_bytes(M, N, K))
+      dw = torch.zeros(M, N, device='cuda')
+      assert fused.wgrad_accumulate_(dw, dy, x)
+      assert float((dw.double() - want).abs().max()) / float(want.abs().max()) < 2e-5
+  finally:
+    L.mmt_wgrad_set_cu_budget(256)
+  assert sizes[0] > sizes[1] > sizes[2]          # fewer split-K slabs with fewer compute units
