@@ -16,6 +16,7 @@
 // dE / dbias: each K4a wave emits its Q^T.dRel partial (MFMA); one fixed-order pass sums them
 // (no atomics, bitwise reproducible).
 #include "attn_tile.h"
+#include "attn_combine.h"
 
 namespace mmt {
 
@@ -374,24 +375,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
 template <typename T>
 __global__ __launch_bounds__(64) void attn_bwd_dq_combine_kernel(const BwdParams p) {
   __shared__ float dr_s[64];
-  const int bn = blockIdx.y, row = blockIdx.x, d = threadIdx.x;
-  const int gblk = row >> 5, rr = row & 31;
-  const int b = bn / p.N, n = bn - b * p.N;
-  const int q = p.pat.g0 + row;
-  const long slot0 = ((long)bn * p.n_gblk + gblk) * p.n_chunks;
-  float acc = 0.f, dr = 0.f;
-  for (int c = 0; c < p.n_chunks; ++c) {
-    acc += p.part_dq[(slot0 + c) * (32 * 64) + rr * 64 + d];
-    if (d < p.Rp) dr += p.part_dtab[(slot0 + c) * (32 * p.Rp) + rr * p.Rp + d];
-  }
-  if (d >= p.R) dr = 0.f;
-  dr_s[d] = dr;
-  if (d < p.Rp) p.drel[((long)bn * p.pat.ng + row) * p.Rp + d] = dr;
-  __syncthreads();
-  const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
-  for (int id = 0; id < p.R; ++id) acc = fmaf(dr_s[id], (float)E[(long)id * p.N * 64 + d], acc);
-  T* DQ = reinterpret_cast<T*>(p.dq) + (long)b * p.qs[0] + (long)q * p.qs[1] + (long)n * p.qs[2];
-  DQ[d] = (T)acc;
+  dq_combine_row<T>(p, blockIdx.y, blockIdx.x, threadIdx.x, dr_s, [] { __syncthreads(); });
 }
 
 // =========================================================================================
@@ -567,19 +551,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkv_ke
 
 template <typename T>
 __global__ __launch_bounds__(64) void attn_bwd_dkv_combine_kernel(const BwdParams p) {
-  const int bn = blockIdx.y, row = blockIdx.x, d = threadIdx.x;
-  const int gblk = row >> 5, rr = row & 31;
-  const int b = bn / p.N, n = bn - b * p.N;
-  const int k = p.pat.g0 + row;
-  const long slot0 = ((long)bn * p.n_gblk + gblk) * p.n_chunks;
-  float ak = 0.f, av = 0.f;
-  for (int c = 0; c < p.n_chunks; ++c) {
-    const float* base = p.part_dkv + (slot0 + c) * (2 * 32 * 64) + rr * 64 + d;
-    ak += base[0];
-    av += base[32 * 64];
-  }
-  reinterpret_cast<T*>(p.dk)[(long)b * p.ks[0] + (long)k * p.ks[1] + (long)n * p.ks[2] + d] = (T)ak;
-  reinterpret_cast<T*>(p.dv)[(long)b * p.vs[0] + (long)k * p.vs[1] + (long)n * p.vs[2] + d] = (T)av;
+  dkv_combine_row<T>(p, blockIdx.y, blockIdx.x, threadIdx.x);
 }
 
 // =========================================================================================
@@ -590,6 +562,11 @@ template <typename T>
 __global__ __launch_bounds__(1024) void drel_reduce_kernel(const BwdParams p) {
   __shared__ float red[16][64], redb[16];
   const int id = blockIdx.x, n = blockIdx.y, d = threadIdx.x & 63, part = threadIdx.x >> 6;
+  if (id >= p.Rp) {            // lean path: the dK/dV combine of the global rows rides along (16 rows per block)
+    const int pair = ((id - p.Rp) * p.N + n) * 16 + part;
+    if (pair < p.pat.ng * p.B * p.N) dkv_combine_row<T>(p, pair / p.pat.ng, pair % p.pat.ng, d);
+    return;
+  }
   if (id >= p.R) return;
   const int per = p.Rp * 64 + p.Rp;
   const int waves_per_bn = p.red_per_plane;       // partial slots per plane (one per wave, or per workgroup)
@@ -694,8 +671,10 @@ hipError_t launch_bwd_dkv_combine(const BwdParams& p, bool bf16, hipStream_t st)
   return hipGetLastError();
 }
 hipError_t launch_drel_reduce(const BwdParams& p, bool bf16, hipStream_t st) {
-  if (bf16) hipLaunchKernelGGL(drel_reduce_kernel<__bf16>, dim3(p.Rp, p.N), dim3(1024), 0, st, p);
-  else hipLaunchKernelGGL(drel_reduce_kernel<float>, dim3(p.Rp, p.N), dim3(1024), 0, st, p);
+  int extra = 0;               // blocks (x >= Rp) that combine the dK/dV partials of the global rows, 16 rows each
+  if (p.comb_in_next && p.n_gblk > 0) extra = (p.pat.ng * p.B * p.N + 16 * p.N - 1) / (16 * p.N);
+  if (bf16) hipLaunchKernelGGL(drel_reduce_kernel<__bf16>, dim3(p.Rp + extra, p.N), dim3(1024), 0, st, p);
+  else hipLaunchKernelGGL(drel_reduce_kernel<float>, dim3(p.Rp + extra, p.N), dim3(1024), 0, st, p);
   return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 //   * row fragments of a tile that is staged in LDS anyway are read back from LDS
 //     (frag_from_tile) instead of being loaded a second time in fragment shape.
 #include "attn_lean.h"
+#include "attn_combine.h"
 
 namespace mmt {
 
@@ -383,6 +384,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   float* rowc = bias_ts + Rp;            // per row of the current q tile: [0,32) lse*log2e, [32,64) delta,
                                          // [64,96) rel(clipped, d<=-m) - lse2, [96,128) rel(clipped, d>=m) - lse2
 
+  if (p.comb_in_next) {          // trailing blocks: the dQ combine of the global rows (one row per wave)
+    const int per_bn0 = (p.n_chunks * p.n_gblk + 3) >> 2;
+    const int n_main = p.n_band_blocks + per_bn0 * p.B * p.N;
+    if ((int)blockIdx.x >= n_main) {
+      const int pair = ((int)blockIdx.x - n_main) * 4 + wave;
+      if (pair < p.pat.ng * p.B * p.N)
+        dq_combine_row<T>(p, pair / p.pat.ng, pair % p.pat.ng, lane, reinterpret_cast<float*>(smem) + wave * 64,
+                          [] { wave_lds_sync(); });
+      return;
+    }
+  }
   const int n_tiles = (p.S + 31) >> 5, nkb = (p.S + 127) >> 7;
   const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
   int bn, k0, chunk = 0, gblk = 0, blk;
@@ -611,6 +623,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
 template <int Rp, bool HAS_REL>
 static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
   BwdParams p = p_in;
+  p.comb_in_next = 0;
   p.red_per_plane = p.red_live = (p.S + 127) >> 7;        // one dE partial per 128-row workgroup
   const int per_bn = (p.n_chunks * p.n_gblk + 3) / 4;
   dim3 grid(p.n_band_blocks + per_bn * p.B * p.N);
@@ -621,10 +634,15 @@ static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
   hipLaunchKernelGGL((attn_bwd_dq_band_bf16_kernel<Rp, HAS_REL>), grid, dim3(256), lds_a, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  if (p.n_gblk > 0 && (e = launch_bwd_dq_combine(p, true, st)) != hipSuccess) return e;
-  hipLaunchKernelGGL((attn_bwd_dkv_band_bf16_kernel<Rp, HAS_REL>), grid, dim3(256), lds_b, st, p);
+  // With a dE reduce to follow, the two combines of the global-token partials ride in the next launches
+  // (attn_combine.h); without one they stay launches of their own.
+  const bool ride = p.n_gblk > 0 && p.R > 0;
+  if (p.n_gblk > 0 && !ride && (e = launch_bwd_dq_combine(p, true, st)) != hipSuccess) return e;
+  p.comb_in_next = ride ? 1 : 0;
+  dim3 grid_kv(grid.x + (ride ? (p.pat.ng * p.B * p.N + 3) / 4 : 0));
+  hipLaunchKernelGGL((attn_bwd_dkv_band_bf16_kernel<Rp, HAS_REL>), grid_kv, dim3(256), lds_b, st, p);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  if (p.n_gblk > 0 && (e = launch_bwd_dkv_combine(p, true, st)) != hipSuccess) return e;
+  if (p.n_gblk > 0 && !ride && (e = launch_bwd_dkv_combine(p, true, st)) != hipSuccess) return e;
   if (p.R > 0) e = launch_drel_reduce(p, true, st);
   return e;
 }
