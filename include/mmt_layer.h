@@ -191,6 +191,22 @@ int mmt_xent_bwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int
                  const int32_t* labels, const float* lse, const float* coef, void* dlogits, int64_t ldd,
                  void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Feed-forward GEMMs with the GELU in the epilogue (bf16 operands, fp32 accumulate; K11, csrc/ffn_gemm.hip).
+ * They replace, for the intermediate Dense of the encoder block (reference: the `inner_activation` Dense pair
+ * of every TransformerEncoderBlock the encoder stacks, mmt_encoder.py:53-54 + 221-238), the sequence
+ * "library GEMM -> mmt_bias_gelu_fwd" and, in the tape's backward, "library GEMM -> mmt_bias_gelu_bwd":
+ *   mmt_ffn_gelu_gemm :  u[M,N] = x[M,K] . w[N,K]^T + bias[N]   (u optional, rounded to bf16)
+ *                        g[M,N] = gelu_tanh(u)                    (of the ROUNDED u, so that the backward, which
+ *                                                                  only has the stored u, sees the same function)
+ *   mmt_ffn_dgelu_gemm:  du[M,N] = (dy[M,K] . w[K,N]) * gelu_tanh'(u[M,N] + bias[N])      (bias may be NULL)
+ * All matrices row-major with row strides ld* in elements (multiples of 8), 16-byte aligned; bias fp32.
+ * Needs M % 256 == 0, N % 256 == 0, K % 64 == 0, otherwise MMT_E_UNSUPPORTED (nothing launched). */
+int mmt_ffn_gelu_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* u,
+                      int64_t ldu, void* g, int64_t ldg, int64_t M, int64_t N, int64_t K, void* stream);
+int mmt_ffn_dgelu_gemm(const void* dy, int64_t lddy, const void* w, int64_t ldw, const void* u, int64_t ldu,
+                       const float* bias, void* du, int64_t lddu, int64_t M, int64_t N, int64_t K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

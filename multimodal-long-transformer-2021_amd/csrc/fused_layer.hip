@@ -246,16 +246,7 @@ hipError_t launch_colsum_reduce(const float* part, int nblocks, int ksets, int H
 // =============================================================================================
 // GELU (tanh approximation, mmt_encoder.py:53-54) with the dense layer's bias folded in.
 // =============================================================================================
-__device__ __forceinline__ float gelu_tanh(float z, float& dz) {
-  const float k = 0.7978845608028654f, c = 0.044715f;
-  const float z2 = z * z;
-  const float inner = k * z * fmaf(c, z2, 1.f);
-  // tanh(a) = 1 - 2 / (1 + 2^(2a*log2e)): v_exp_f32 + v_rcp_f32, saturates cleanly at +-1
-  const float e = __builtin_amdgcn_exp2f(inner * (2.f * kLog2e));
-  const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
-  dz = 0.5f * (1.f + t) + 0.5f * z * (1.f - t * t) * k * fmaf(3.f * c, z2, 1.f);
-  return 0.5f * z * (1.f + t);
-}
+// gelu_tanh(): layer_common.h
 
 // thread = one 8-column chunk (blockIdx.x * 256 + tid), rows strided by gridDim.y
 template <typename T, bool BWD>

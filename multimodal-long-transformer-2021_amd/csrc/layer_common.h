@@ -101,9 +101,38 @@ __host__ __device__ __forceinline__ uint32_t drop_bits16(uint32_t seed_lo, uint3
   return (idx & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
 }
 
+// GELU, tanh approximation (mmt_encoder.py:53-54): returns gelu(z), dz = gelu'(z).
+__device__ __forceinline__ float gelu_tanh(float z, float& dz) {
+  const float k = 0.7978845608028654f, c = 0.044715f;
+  const float z2 = z * z;
+  const float inner = k * z * fmaf(c, z2, 1.f);
+  // tanh(a) = 1 - 2 / (1 + 2^(2a*log2e)): v_exp_f32 + v_rcp_f32, saturates cleanly at +-1
+  const float e = __builtin_amdgcn_exp2f(inner * (2.f * kLog2e));
+  const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e);
+  dz = 0.5f * (1.f + t) + 0.5f * z * (1.f - t * t) * k * fmaf(3.f * c, z2, 1.f);
+  return 0.5f * z * (1.f + t);
+}
+
+// The same function on a pair of values with packed fp32 arithmetic (v_pk_mul/fma_f32), written in terms of
+// s = 1 / (1 + 2^(2 a log2e)) = (1 - tanh a) / 2:   gelu = z (1 - s),   gelu' = (1 - s)(1 + 2 k z s (1 + 3 c z^2)).
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ f32x2 gelu_tanh_x2(f32x2 z, f32x2& dz) {
+  const float k = 0.7978845608028654f, c = 0.044715f;
+  const f32x2 z2 = z * z;
+  const f32x2 a = (z * (2.f * k * kLog2e)) * (z2 * c + 1.f);
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])} + 1.f;
+  const f32x2 sg = f32x2{__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+  const f32x2 q = 1.f - sg;
+  dz = q * (((z * sg) * (z2 * (3.f * c) + 1.f)) * (2.f * k) + 1.f);
+  return z * q;
+}
+
 // out[j][col] (+)= sum_blocks part[block][j][col] in fixed order (fused_layer.hip).
 hipError_t launch_colsum_reduce(const float* part, int nblocks, int ksets, int H, float* o0, float* o1,
                                 float* o2, int accumulate, hipStream_t st);
+
+// Compute units a full-chip GEMM grid may fill (mmt_wgrad_set_cu_budget; wgrad_gemm.hip).
+int cu_budget();
 
 // 16-bit dropout threshold and the exact inverse keep probability of the 16-bit test.
 inline unsigned dropout_thresh16(float p) {

@@ -227,10 +227,57 @@ class _BiasGeluFn(torch.autograd.Function):
     return du.view(ctx.shape), _finish(ctx.param, dbias, direct)
 
 
+def bias_gelu_forward_(u2: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+  """gelu_tanh(u2 + bias) for a contiguous [rows, H] u2, outside autograd (callers own the backward)."""
+  _check(u2, bias)
+  y = torch.empty_like(u2)
+  with torch.cuda.device(u2.device):
+    _lib.check(_lib.lib().mmt_bias_gelu_fwd(_desc(u2), _p(u2), _p(_f32(bias)), _p(y), _stream(u2)))
+  return y
+
+
 def bias_gelu(u, bias):
   """gelu_tanh(u + bias)."""
   return _BiasGeluFn.apply(u, bias)
 
+
+
+def _ffn_gemm_ok(a: torch.Tensor, w: torch.Tensor, M: int, N: int, K: int) -> bool:
+  return (a.is_cuda and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and M % 256 == 0 and N % 256 == 0
+          and K % 64 == 0 and a.stride(1) == 1 and w.stride(1) == 1 and a.stride(0) % 8 == 0 and w.stride(0) % 8 == 0
+          and a.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
+def ffn_gelu_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor]):
+  """(u, g) with u = x[M,K] @ w[N,K]^T + bias (bf16), g = gelu_tanh(u): one hand-written GEMM with the
+  activation in its epilogue (`mmt_ffn_gelu_gemm`).  Returns None when the shape is outside the kernel's."""
+  M, K = x.shape
+  N = w.shape[0]
+  if not (w.shape[1] == K and _ffn_gemm_ok(x, w, M, N, K)
+          and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N))):
+    return None
+  u = torch.empty(M, N, device=x.device, dtype=torch.bfloat16)
+  g = torch.empty_like(u)
+  with torch.cuda.device(x.device):
+    _lib.check(_lib.lib().mmt_ffn_gelu_gemm(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias) if bias is not None else None,
+                                            _p(u), N, _p(g), N, M, N, K, _stream(x)))
+  return u, g
+
+
+def ffn_dgelu_gemm(dy: torch.Tensor, w: torch.Tensor, u: torch.Tensor, bias: Optional[torch.Tensor] = None):
+  """du = (dy[M,K] @ w[K,N]) * gelu_tanh'(u[M,N] (+ bias)) in one GEMM (`mmt_ffn_dgelu_gemm`); None when the
+  shape is outside the kernel's."""
+  M, K = dy.shape
+  N = w.shape[1]
+  if not (w.shape[0] == K and u.shape == (M, N) and u.dtype == torch.bfloat16 and u.stride(1) == 1
+          and u.stride(0) % 8 == 0 and u.data_ptr() % 16 == 0 and _ffn_gemm_ok(dy, w, M, N, K)
+          and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N))):
+    return None
+  du = torch.empty(M, N, device=dy.device, dtype=torch.bfloat16)
+  with torch.cuda.device(dy.device):
+    _lib.check(_lib.lib().mmt_ffn_dgelu_gemm(_p(dy), dy.stride(0), _p(w), w.stride(0), _p(u), u.stride(0),
+                                             _p(bias) if bias is not None else None, _p(du), N, M, N, K, _stream(dy)))
+  return du
 
 def accumulate_grad_(acc: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
   """acc (fp32, contiguous) += g (fp32 | bf16), one streaming kernel."""

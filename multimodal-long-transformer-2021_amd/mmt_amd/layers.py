@@ -9,6 +9,7 @@ torch is the buffer carrier / autograd glue; the attention core runs in the HIP 
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, Optional
 
 import torch
@@ -72,6 +73,10 @@ def cast_param(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
   return _CastParamFn.apply(param, dtype)
 
 
+_FFN_FUSED = os.environ.get('MMT_FFN_FUSED', '1') != '0'
+_FFN_FWD_FUSED = os.environ.get('MMT_FFN_FWD_FUSED', '0') != '0'
+
+
 def _param_weight(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
   shadow = getattr(param, '_mmt_shadow', None)
   return shadow if (shadow is not None and shadow.dtype == dtype) else param.detach().to(dtype)
@@ -80,6 +85,35 @@ def _param_weight(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 def _notify(param):
   for hook in getattr(param, '_mmt_grad_ready_hooks', ()):
     hook(param)
+
+
+def _accumulate_dense_grads(weight, bias, dy2, x2):
+  """weight.grad (fp32) += dy2^T @ x2 and bias.grad += dy2.sum(0) for a Dense layer y = x W^T + b, written
+  straight into the master gradients: the hand-written split-K kernel (bias column sums fused, on the
+  weight-gradient side stream when allowed), else library GEMM + accumulate.  Runs the parameters'
+  gradient-ready hooks once the writes are enqueued."""
+  want_b = bias is not None and bias.requires_grad
+  b_done = False
+  if weight.requires_grad:
+    if weight.grad is None:
+      weight.grad = torch.zeros_like(weight, dtype=torch.float32)
+    fuse_b = want_b and bias.grad is not None and bias.grad.dtype == torch.float32 and bias.grad.is_contiguous()
+    wgrad = fused.wgrad_accumulate_side_ if fused.side_stream_ok(weight, bias) else fused.wgrad_accumulate_
+    if weight.grad.dtype == torch.float32 and wgrad(weight.grad, dy2, x2, bias.grad if fuse_b else None):
+      b_done = fuse_b
+    elif weight.grad.dtype == torch.float32:
+      fused.accumulate_grad_(weight.grad, torch.mm(dy2.t(), x2))
+    else:
+      weight.grad.add_(torch.mm(dy2.t(), x2))
+    _notify(weight)
+  if want_b:
+    if not b_done:
+      db = dy2.sum(0, dtype=torch.float32)
+      if bias.grad is None:
+        bias.grad = db.to(bias.dtype)
+      else:
+        bias.grad.add_(db)
+    _notify(bias)
 
 
 class _LinearFn(torch.autograd.Function):
@@ -105,29 +139,53 @@ class _LinearFn(torch.autograd.Function):
     if not dy2.is_contiguous():
       dy2 = dy2.contiguous()
     dx = torch.mm(dy2, w).view(x.shape) if ctx.needs_input_grad[0] else None
-    want_b = bias is not None and bias.requires_grad
-    b_done = False
-    if weight.requires_grad:
-      if weight.grad is None:
-        weight.grad = torch.zeros_like(weight, dtype=torch.float32)
-      fuse_b = want_b and bias.grad is not None and bias.grad.dtype == torch.float32 and bias.grad.is_contiguous()
-      wgrad = fused.wgrad_accumulate_side_ if fused.side_stream_ok(weight, bias) else fused.wgrad_accumulate_
-      if weight.grad.dtype == torch.float32 and wgrad(weight.grad, dy2, x2, bias.grad if fuse_b else None):
-        b_done = fuse_b
-      elif weight.grad.dtype == torch.float32:
-        fused.accumulate_grad_(weight.grad, torch.mm(dy2.t(), x2))
-      else:
-        weight.grad.add_(torch.mm(dy2.t(), x2))
-      _notify(weight)
-    if want_b:
-      if not b_done:
-        db = dy2.sum(0, dtype=torch.float32)
-        if bias.grad is None:
-          bias.grad = db.to(bias.dtype)
-        else:
-          bias.grad.add_(db)
-      _notify(bias)
+    _accumulate_dense_grads(weight, bias, dy2, x2)
     return dx, None, None
+
+
+class _FfnFn(torch.autograd.Function):
+  """f = gelu_tanh(x @ W1^T + b1) @ W2^T: the feed-forward pair of one encoder block with the activation inside
+  the GEMM epilogues (`mmt_ffn_gelu_gemm` forward when `MMT_FFN_FWD_FUSED`, `mmt_ffn_dgelu_gemm` backward), so
+  the [B*S, 4H] intermediate is not swept by a separate activation pass.  Parameter gradients as `_LinearFn`."""
+
+  @staticmethod
+  def forward(ctx, x, w1, b1, w2):
+    w1s, w2s = _param_weight(w1, x.dtype), _param_weight(w2, x.dtype)
+    x2 = x.reshape(-1, x.shape[-1])
+    if not x2.is_contiguous():
+      x2 = x2.contiguous()
+    ug = fused.ffn_gelu_gemm(x2, w1s, b1.detach()) if _FFN_FWD_FUSED else None
+    ctx.u_has_bias = ug is not None
+    if ug is None:                       # library GEMM + activation pass; u is kept WITHOUT the bias
+      u = F.linear(x2, w1s)
+      g = fused.bias_gelu_forward_(u, b1.detach())
+    else:
+      u, g = ug
+    ctx.save_for_backward(x2, u, g, w1s, w2s)
+    ctx.params = (w1, b1, w2)
+    ctx.shape = x.shape
+    return F.linear(g, w2s).view(*x.shape[:-1], w2.shape[0])
+
+  @staticmethod
+  def backward(ctx, df):
+    x2, u, g, w1s, w2s = ctx.saved_tensors
+    w1, b1, w2 = ctx.params
+    df2 = df.reshape(-1, df.shape[-1])
+    if not df2.is_contiguous():
+      df2 = df2.contiguous()
+    _accumulate_dense_grads(w2, None, df2, g)
+    du = fused.ffn_dgelu_gemm(df2, w2s, u, None if ctx.u_has_bias else b1.detach())
+    if du is None:
+      raise RuntimeError('mmt_ffn_dgelu_gemm refused a shape _ffn_ok admitted')
+    _accumulate_dense_grads(w1, b1, du, x2)
+    dx = torch.mm(du, w1s).view(ctx.shape) if ctx.needs_input_grad[0] else None
+    return dx, None, None, None
+
+
+def _ffn_ok(x, w1, b1, w2) -> bool:
+  return (x.is_cuda and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
+          and all(isinstance(t, nn.Parameter) and t.dtype == torch.float32 for t in (w1, b1, w2))
+          and x.numel() // x.shape[-1] % 256 == 0 and w1.shape[0] % 256 == 0 and x.shape[-1] % 64 == 0)
 
 
 def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
@@ -333,9 +391,12 @@ class RelativeTransformerLayers(nn.Module):
       ln2 = layer.ffn_layer_norm
       x, h2 = fused.residual_block(o, layer.attention.output_bias, x, ln2.weight, ln2.bias, ln2.eps,
                                    p, fused.next_seed(dropout_seed) if p else 0)
-      u = _linear(h2, layer.intermediate_weight, None)
-      y = fused.bias_gelu(u, layer.intermediate_bias)
-      f = _linear(y, layer.ffn_output_weight, None)
+      if _FFN_FUSED and _ffn_ok(h2, layer.intermediate_weight, layer.intermediate_bias, layer.ffn_output_weight):
+        f = _FfnFn.apply(h2, layer.intermediate_weight, layer.intermediate_bias, layer.ffn_output_weight)
+      else:
+        u = _linear(h2, layer.intermediate_weight, None)
+        y = fused.bias_gelu(u, layer.intermediate_bias)
+        f = _linear(y, layer.ffn_output_weight, None)
       nxt = self.layers[i + 1].attention_layer_norm if i + 1 < L else None
       x, h = fused.residual_block(f, layer.ffn_output_bias, x,
                                   None if nxt is None else nxt.weight, None if nxt is None else nxt.bias,

@@ -268,3 +268,97 @@ def test_wgrad_cu_budget_changes_the_split_not_the_result():
   finally:
     L.mmt_wgrad_set_cu_budget(256)
   assert sizes[0] > sizes[1] > sizes[2]          # fewer split-K slabs with fewer compute units
+
+
+# ---- K11: feed-forward GEMMs with the GELU in the epilogue (mmt_ffn_gelu_gemm / mmt_ffn_dgelu_gemm) ---------
+# bf16 operands, fp32 accumulate: compared with the numpy oracle on the bf16-rounded inputs; tolerance = one
+# bf16 rounding of the output (2^-8 relative) plus 2e-3 for accumulation order / the hardware exp and rcp.
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 192), (1024, 256, 768)])
+@pytest.mark.parametrize('with_bias', [True, False])
+def test_ffn_gelu_gemm_matches_oracle(M, N, K, with_bias):
+  from mmt_amd import fused
+  rng = np.random.default_rng(M + N + K)
+  x = bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+  w = bf16_round((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32) * 2)
+  b = rng.standard_normal(N).astype(np.float32) if with_bias else None
+  out = fused.ffn_gelu_gemm(_dev(x, torch.bfloat16), _dev(w, torch.bfloat16), None if b is None else _dev(b))
+  assert out is not None
+  u, g = (t.float().cpu().numpy() for t in out)
+  u_ref = x.astype(np.float64) @ w.astype(np.float64).T + (0 if b is None else b)
+  close = lambda got, ref: bool((np.abs(got - ref) <= 2.0 ** -8 * np.abs(ref) + 2e-3).all())     # one bf16 rounding
+  assert close(u, u_ref)
+  assert close(g, lo.gelu_tanh(u.astype(np.float64)))          # gelu of the STORED (rounded) u
+  assert fused.ffn_gelu_gemm(_dev(x[:100], torch.bfloat16), _dev(w, torch.bfloat16), None) is None   # M % 256 != 0
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (512, 768, 192), (768, 1024, 256)])
+@pytest.mark.parametrize('with_bias', [True, False])
+def test_ffn_dgelu_gemm_matches_oracle(M, N, K, with_bias):
+  from mmt_amd import fused
+  rng = np.random.default_rng(M + 3 * N + K)
+  dy = bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+  w = bf16_round((rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32) * 2)
+  u = bf16_round(rng.standard_normal((M, N)).astype(np.float32) * 2)
+  b = rng.standard_normal(N).astype(np.float32) if with_bias else None
+  du = fused.ffn_dgelu_gemm(_dev(dy, torch.bfloat16), _dev(w, torch.bfloat16), _dev(u, torch.bfloat16),
+                            None if b is None else _dev(b))
+  assert du is not None
+  ref = (dy.astype(np.float64) @ w.astype(np.float64)) * lo.gelu_tanh_grad(u.astype(np.float64) + (0 if b is None else b))
+  assert (np.abs(du.float().cpu().numpy() - ref) <= 2.0 ** -8 * np.abs(ref) + 2e-3).all()       # one bf16 rounding
+  # a strided (column-sliced) dy is accepted through its row stride
+  wide = torch.zeros(M, K + 64, device='cuda', dtype=torch.bfloat16)
+  wide[:, :K] = _dev(dy, torch.bfloat16)
+  du2 = fused.ffn_dgelu_gemm(wide[:, :K], _dev(w, torch.bfloat16), _dev(u, torch.bfloat16), None if b is None else _dev(b))
+  assert torch.equal(du2, du)
+
+
+@pytest.mark.parametrize('fwd_fused', [False, True])
+def test_ffn_fn_matches_unfused_pair(fwd_fused, monkeypatch):
+  """`_FfnFn` (activation inside the GEMM epilogues) against the library-GEMM + bias_gelu chain it replaces."""
+  from mmt_amd import fused, layers
+  monkeypatch.setattr(layers, '_FFN_FWD_FUSED', fwd_fused)
+  torch.manual_seed(1)
+  H, Fd = 128, 512
+  mk = lambda *s: torch.nn.Parameter(torch.randn(*s, device='cuda') * 0.08)
+  w1, b1, w2 = mk(Fd, H), mk(Fd), mk(H, Fd)
+  x = torch.randn(2, 128, H, device='cuda', dtype=torch.bfloat16, requires_grad=True)
+  go = torch.randn(2, 128, H, device='cuda', dtype=torch.bfloat16)
+  assert layers._ffn_ok(x, w1, b1, w2)
+  f = layers._FfnFn.apply(x, w1, b1, w2)
+  f.backward(go)
+  got = [f.detach().float(), x.grad.float(), w1.grad.clone(), b1.grad.clone(), w2.grad.clone()]
+  x.grad = None
+  for t in (w1, b1, w2):
+    t.grad = None
+  f2 = layers._linear(fused.bias_gelu(layers._linear(x, w1, None), b1), w2, None)
+  f2.backward(go)
+  want = [f2.detach().float(), x.grad.float(), w1.grad, b1.grad, w2.grad]
+  for a, b, name in zip(got, want, ('f', 'dx', 'dw1', 'db1', 'dw2')):
+    assert float((a - b).abs().max()) <= 2e-2 * max(1.0, float(b.abs().max())), name
+
+
+def test_ffn_gemm_cu_budget_changes_the_schedule_not_the_result():
+  """The persistent kernels size their grid for the CU budget; every budget must give the same bits."""
+  from mmt_amd import fused, _lib
+  torch.manual_seed(3)
+  x = torch.randn(2048, 192, device='cuda').bfloat16()
+  w1 = (torch.randn(768, 192, device='cuda') * 0.1).bfloat16()
+  w2 = (torch.randn(192, 768, device='cuda') * 0.1).bfloat16()
+  b1 = torch.randn(768, device='cuda')
+  try:
+    outs = []
+    for cus in (256, 40, 32):                        # 24 tiles: 1, 1 and 1 tile(s) per workgroup; 32 < 24*... see below
+      _lib.lib().mmt_wgrad_set_cu_budget(cus)
+      u, g = fused.ffn_gelu_gemm(x, w1, b1)
+      du = fused.ffn_dgelu_gemm(x, w2, u)
+      outs.append((u, g, du))
+    big = torch.randn(8192, 192, device='cuda').bfloat16()        # 96 tiles on 32 CUs: 3 per workgroup
+    _lib.lib().mmt_wgrad_set_cu_budget(32)
+    a = fused.ffn_gelu_gemm(big, w1, b1)
+    _lib.lib().mmt_wgrad_set_cu_budget(256)
+    b = fused.ffn_gelu_gemm(big, w1, b1)
+  finally:
+    _lib.lib().mmt_wgrad_set_cu_budget(256)
+  for o in outs[1:]:
+    assert all(torch.equal(p, q) for p, q in zip(o, outs[0]))
+  assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
