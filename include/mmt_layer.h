@@ -201,7 +201,10 @@ int mmt_xent_bwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int
  *                                                                  only has the stored u, sees the same function)
  *   mmt_ffn_dgelu_gemm:  du[M,N] = (dy[M,K] . w[K,N]) * gelu_tanh'(u[M,N] + bias[N])      (bias may be NULL)
  * All matrices row-major with row strides ld* in elements (multiples of 8), 16-byte aligned; bias fp32.
- * Needs M % 256 == 0, N % 256 == 0, K % 64 == 0, otherwise MMT_E_UNSUPPORTED (nothing launched). */
+ * Needs M % 256 == 0, N % 256 == 0, K % 64 == 0, otherwise MMT_E_UNSUPPORTED (nothing launched).
+ * The kernels are persistent, one workgroup per compute unit: mmt_ffn_set_cu_budget (default 256, clamped to
+ * [32, 256], process-wide) sizes the grid, e.g. to leave units to collective kernels that overlap backward. */
+void mmt_ffn_set_cu_budget(int32_t cus);
 int mmt_ffn_gelu_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* u,
                       int64_t ldu, void* g, int64_t ldg, int64_t M, int64_t N, int64_t K, void* stream);
 int mmt_ffn_dgelu_gemm(const void* dy, int64_t lddy, const void* w, int64_t ldw, const void* u, int64_t ldu,

@@ -27,6 +27,8 @@
 #include "layer_common.h"
 #include "mmt_err.h"
 
+#include <atomic>
+
 namespace mmt {
 
 struct FfnGemmParams {
@@ -39,6 +41,10 @@ struct FfnGemmParams {
   long lda, ldb, ldu, ldd;
   int M, N, K, tiles_m, tiles_n, tiles_per_wg;
 };
+
+// Compute units the persistent grid may fill (mmt_ffn_set_cu_budget).
+static std::atomic<int> g_ffn_cus{256};
+static int cu_budget() { return g_ffn_cus.load(std::memory_order_relaxed); }
 
 constexpr int kFfnStage = 64 * 1024;
 enum { kEpiBias = 0, kEpiGelu = 1, kEpiDgelu = 2 };
@@ -246,6 +252,10 @@ static int ffn_check(const char* who, const void* a, const void* b, const void* 
 }
 
 }  // namespace mmt
+
+extern "C" void mmt_ffn_set_cu_budget(int32_t cus) {
+  mmt::g_ffn_cus.store(cus < 32 ? 32 : (cus > 256 ? 256 : cus), std::memory_order_relaxed);
+}
 
 extern "C" int mmt_ffn_gelu_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw, const float* bias, void* u,
                                  int64_t ldu, void* g, int64_t ldg, int64_t M, int64_t N, int64_t K, void* stream) {

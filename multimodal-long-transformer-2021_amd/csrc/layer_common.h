@@ -131,9 +131,6 @@ __device__ __forceinline__ f32x2 gelu_tanh_x2(f32x2 z, f32x2& dz) {
 hipError_t launch_colsum_reduce(const float* part, int nblocks, int ksets, int H, float* o0, float* o1,
                                 float* o2, int accumulate, hipStream_t st);
 
-// Compute units a full-chip GEMM grid may fill (mmt_wgrad_set_cu_budget; wgrad_gemm.hip).
-int cu_budget();
-
 // 16-bit dropout threshold and the exact inverse keep probability of the 16-bit test.
 inline unsigned dropout_thresh16(float p) {
   if (!(p > 0.f)) return 0;

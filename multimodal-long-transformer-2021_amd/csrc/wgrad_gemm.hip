@@ -414,10 +414,6 @@ int wgrad_split(int tiles, long K, int tile_m) {
 }
 }  // namespace
 
-namespace mmt {
-int cu_budget() { return g_cu_budget.load(std::memory_order_relaxed); }
-}  // namespace mmt
-
 extern "C" void mmt_wgrad_set_cu_budget(int32_t cus) {
   g_cu_budget.store(cus < 32 ? 32 : (cus > 256 ? 256 : cus), std::memory_order_relaxed);
 }

@@ -25,7 +25,7 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
            'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_colsum_reduce', 'mmt_accumulate_grad', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
            'mmt_wgrad_bias_accumulate', 'mmt_wgrad_workspace_bytes', 'mmt_wgrad_set_cu_budget', 'mmt_embed_fwd', 'mmt_embed_bwd',
-           'mmt_embed_workspace_bytes', 'mmt_xent_fwd', 'mmt_xent_bwd', 'mmt_ffn_gelu_gemm', 'mmt_ffn_dgelu_gemm')
+           'mmt_embed_workspace_bytes', 'mmt_xent_fwd', 'mmt_xent_bwd', 'mmt_ffn_gelu_gemm', 'mmt_ffn_dgelu_gemm', 'mmt_ffn_set_cu_budget')
 
 
 class EmbedDesc(ctypes.Structure):
@@ -150,6 +150,8 @@ def lib() -> ctypes.CDLL:
   L.mmt_ffn_gelu_gemm.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, i64, i64, vp]
   L.mmt_ffn_dgelu_gemm.restype = ctypes.c_int
   L.mmt_ffn_dgelu_gemm.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, i64, i64, i64, i64, vp]
+  L.mmt_ffn_set_cu_budget.restype = None
+  L.mmt_ffn_set_cu_budget.argtypes = [ctypes.c_int32]
   L.mmt_wgrad_set_cu_budget.restype = None
   L.mmt_wgrad_set_cu_budget.argtypes = [ctypes.c_int32]
   L.mmt_wgrad_workspace_bytes.restype = ctypes.c_size_t

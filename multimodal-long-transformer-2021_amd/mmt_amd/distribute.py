@@ -116,6 +116,7 @@ class GradientBucketReducer:
         # leave compute units to the RCCL kernels that run under backward (csrc/wgrad_gemm.hip)
         from . import _lib
         _lib.lib().mmt_wgrad_set_cu_budget(int(os.environ.get('MMT_WGRAD_CUS', '224')))
+        _lib.lib().mmt_ffn_set_cu_budget(int(os.environ.get('MMT_WGRAD_CUS', '224')))
       for p in self.params:
         p.register_post_accumulate_grad_hook(self._on_grad_ready)
         # Kernels that add a gradient straight into `.grad` (weight-gradient GEMM, fused-layer column

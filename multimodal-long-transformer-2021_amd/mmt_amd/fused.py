@@ -339,8 +339,10 @@ def _side_stream(device):
   if s is None:
     s = _SIDE[device] = torch.cuda.Stream(device=device)
     # the GEMMs on this stream co-run with the critical-path kernels: a grid that leaves them some compute
-    # units measured 0.1 ms/step faster than one sized for the whole chip (224 vs 256; 192-240 are flat)
+    # units measured 0.1 ms/step faster than one sized for the whole chip (224 vs 256; 192-240 are flat); the
+    # persistent dgelu GEMM on the main stream likewise (192-224 workgroups: 16.63-16.69 ms/step, 256: 16.73)
     _lib.lib().mmt_wgrad_set_cu_budget(int(os.environ.get('MMT_WGRAD_CUS', '224')))
+    _lib.lib().mmt_ffn_set_cu_budget(int(os.environ.get('MMT_FFN_CUS', '224')))
   return s
 
 

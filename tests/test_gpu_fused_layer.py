@@ -347,18 +347,18 @@ def test_ffn_gemm_cu_budget_changes_the_schedule_not_the_result():
   b1 = torch.randn(768, device='cuda')
   try:
     outs = []
-    for cus in (256, 40, 32):                        # 24 tiles: 1, 1 and 1 tile(s) per workgroup; 32 < 24*... see below
-      _lib.lib().mmt_wgrad_set_cu_budget(cus)
+    for cus in (256, 40, 32):                        # 24 tiles: one per workgroup whatever the budget
+      _lib.lib().mmt_ffn_set_cu_budget(cus)
       u, g = fused.ffn_gelu_gemm(x, w1, b1)
       du = fused.ffn_dgelu_gemm(x, w2, u)
       outs.append((u, g, du))
     big = torch.randn(8192, 192, device='cuda').bfloat16()        # 96 tiles on 32 CUs: 3 per workgroup
-    _lib.lib().mmt_wgrad_set_cu_budget(32)
+    _lib.lib().mmt_ffn_set_cu_budget(32)
     a = fused.ffn_gelu_gemm(big, w1, b1)
-    _lib.lib().mmt_wgrad_set_cu_budget(256)
+    _lib.lib().mmt_ffn_set_cu_budget(256)
     b = fused.ffn_gelu_gemm(big, w1, b1)
   finally:
-    _lib.lib().mmt_wgrad_set_cu_budget(256)
+    _lib.lib().mmt_ffn_set_cu_budget(256)
   for o in outs[1:]:
     assert all(torch.equal(p, q) for p, q in zip(o, outs[0]))
   assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
