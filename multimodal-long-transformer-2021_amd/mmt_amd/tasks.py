@@ -9,7 +9,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import configs, input_utils, layers, models
+from . import configs, gemm_tuning, input_utils, layers, models
 
 _TASKS = {}
 
@@ -44,6 +44,7 @@ class _TaskBase:
     self.num_replicas = num_replicas
 
   def _build_encoder(self, encoder_cfg):
+    gemm_tuning.ensure()            # measured library-GEMM selections for the BASELINE shapes (no-op on CPU)
     data_cfg = self.task_config.train_data
     return configs.build_encoder(encoder_cfg, compute_dtype=self.compute_dtype,
                                  patch_embedding_size=data_cfg.patch_size ** 2 * 3)
