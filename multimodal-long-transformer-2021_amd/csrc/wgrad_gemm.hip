@@ -259,9 +259,17 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) 
   }
   const long astep = 64 * p.ldy, bstep = 64 * p.ldx;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  auto dma = [&](unsigned stage, int step) {
+  // `part` < 0: all eight of this wave's DMA instructions; else instructions 2*part, 2*part+1.  Inside the main
+  // loop they are issued two per k-substep, between the MFMA groups: issued back to back, 64 x 1 KiB per
+  // workgroup overrun the memory pipe's queue and the waves that come last sit in the issue for ~2000 cycles
+  // (in-kernel timestamps: half a step) before they reach their MFMAs.  Worth ~2 %: a step stays at 3500-4000
+  // cycles because the matrix pipe (64 MFMAs per SIMD = 2048), the LDS (192 KiB of fragment reads + 64 KiB of
+  // DMA writes = 2048) and the DMA path (64 KiB at the ~32 B/clk it sustains = 2000) all need about the same
+  // time and overlap imperfectly; how the eight instructions are spread over the substeps makes no difference.
+  auto dma = [&](unsigned stage, int step, int part) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
+      if (part >= 0 && (j >> 1) != part) continue;
       const int tile8 = ((wave * 8 + j) >> 2) & 7;
       const __bf16* g = gsrc[j] + (long)step * (tile8 < 4 ? astep : bstep);
       glds16(g, stage + ldst[j]);
@@ -286,15 +294,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) 
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int bch = tid & 31, brow0 = tid >> 5;
 
-  dma(lds0, 0);
+  dma(lds0, 0, -1);
   wait_dma();
   __syncthreads();
 
   for (int step = 0; step < n_steps; ++step) {
     unsigned char* cur = smem + (step & 1) * kDmaStageBytes;
-    if (step + 1 < n_steps) dma(lds0 + ((step + 1) & 1) * kDmaStageBytes, step + 1);         // lands during this step's MFMAs
+    const bool more = step + 1 < n_steps;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
+      if (more) dma(lds0 + ((step + 1) & 1) * kDmaStageBytes, step + 1, s);         // lands during this step's MFMAs
       const unsigned char* slab = cur + (s >> 1) * (8 * 4096) + (s & 1) * 2048;
       bf16x8 af[2], bfr[4];
 #pragma unroll
