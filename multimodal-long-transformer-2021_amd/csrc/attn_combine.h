@@ -19,10 +19,19 @@ __device__ __forceinline__ void dq_combine_row(const BwdParams& p, int bn, int r
   const int q = p.pat.g0 + row;
   const long slot0 = ((long)bn * p.n_gblk + gblk) * p.n_chunks;
   float acc = 0.f, dr = 0.f;
-  for (int c = 0; c < p.n_chunks; ++c) {
-    acc += p.part_dq[(slot0 + c) * (32 * 64) + rr * 64 + d];
-    if (d < p.Rp) dr += p.part_dtab[(slot0 + c) * (32 * p.Rp) + rr * p.Rp + d];
+  const float* pq = p.part_dq + slot0 * (32 * 64) + rr * 64 + d;
+  const float* pt = p.part_dtab + slot0 * (32 * p.Rp) + rr * p.Rp + (d < p.Rp ? d : 0);
+  const long tq = 32 * 64, tt = 32 * p.Rp;
+  int c = 0;
+  for (; c + 4 <= p.n_chunks; c += 4) {          // four chunks' loads in flight, summed in chunk order
+    float a[4], t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = pq[(c + u) * tq]; t[u] = pt[(c + u) * tt]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc += a[u]; dr += t[u]; }
   }
+  for (; c < p.n_chunks; ++c) { acc += pq[c * tq]; dr += pt[c * tt]; }
+  if (d >= p.Rp) dr = 0.f;
   if (d >= p.R) dr = 0.f;
   dr_s[d] = dr;
   if (d < p.Rp) p.drel[((long)bn * p.pat.ng + row) * p.Rp + d] = dr;
@@ -41,11 +50,16 @@ __device__ __forceinline__ void dkv_combine_row(const BwdParams& p, int bn, int 
   const int k = p.pat.g0 + row;
   const long slot0 = ((long)bn * p.n_gblk + gblk) * p.n_chunks;
   float ak = 0.f, av = 0.f;
-  for (int c = 0; c < p.n_chunks; ++c) {
-    const float* base = p.part_dkv + (slot0 + c) * (2 * 32 * 64) + rr * 64 + d;
-    ak += base[0];
-    av += base[32 * 64];
+  const float* base = p.part_dkv + slot0 * (2 * 32 * 64) + rr * 64 + d;
+  int c = 0;
+  for (; c + 4 <= p.n_chunks; c += 4) {
+    float a[4], t[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[u] = base[(long)(c + u) * (2 * 32 * 64)]; t[u] = base[(long)(c + u) * (2 * 32 * 64) + 32 * 64]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { ak += a[u]; av += t[u]; }
   }
+  for (; c < p.n_chunks; ++c) { ak += base[(long)c * (2 * 32 * 64)]; av += base[(long)c * (2 * 32 * 64) + 32 * 64]; }
   reinterpret_cast<T*>(p.dk)[(long)b * p.ks[0] + (long)k * p.ks[1] + (long)n * p.ks[2] + d] = (T)ak;
   reinterpret_cast<T*>(p.dv)[(long)b * p.vs[0] + (long)k * p.vs[1] + (long)n * p.vs[2] + d] = (T)av;
 }

@@ -288,6 +288,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
 }
 
 // Combine the per-chunk partials of the global rows: one wave per (row, bn), lane = d.
+// The chunk statistics are fetched one chunk per LANE (one load instruction, wave reductions) and the
+// partial rows with all loads of a group of eight in flight -- a loop of dependent scalar loads made this
+// 2 KB-per-wave kernel take 10 us, one L2 latency per chunk.
 template <typename T>
 __global__ __launch_bounds__(64) void attn_rows_combine_kernel(const FwdParams p) {
   const int bn = blockIdx.y;
@@ -296,13 +299,35 @@ __global__ __launch_bounds__(64) void attn_rows_combine_kernel(const FwdParams p
   const int rowblk = row >> 5, rr = row & 31;
   const int b = bn / p.N, n = bn - b * p.N;
   const long slot0 = ((long)bn * p.n_rowblk + rowblk) * p.n_chunks;
-  float M = -INFINITY;
-  for (int c = 0; c < p.n_chunks; ++c) M = fmaxf(M, p.part_ml[(slot0 + c) * 64 + rr]);
-  float L = 0.f, acc = 0.f;
-  for (int c = 0; c < p.n_chunks; ++c) {
-    const float w = exp2f(p.part_ml[(slot0 + c) * 64 + rr] - M);
-    L += w * p.part_ml[(slot0 + c) * 64 + 32 + rr];
-    acc += w * p.part_o[(slot0 + c) * (32 * 64) + rr * 64 + d];
+  float L = 0.f, acc = 0.f, M = -INFINITY;
+  for (int c0 = 0; c0 < p.n_chunks; c0 += 64) {             // 64 chunks per pass (one pass in practice)
+    const int c = c0 + d;
+    const bool live = c < p.n_chunks;
+    const float mc = live ? p.part_ml[(slot0 + c) * 64 + rr] : -INFINITY;
+    const float lc = live ? p.part_ml[(slot0 + c) * 64 + 32 + rr] : 0.f;
+    float Mn = mc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) Mn = fmaxf(Mn, __shfl_xor(Mn, o, 64));
+    Mn = fmaxf(Mn, M);
+    const float rescale = exp2f(M - Mn);                    // 0 on the first pass (M = -inf)
+    const float wc = live ? exp2f(mc - Mn) : 0.f;
+    float ls = wc * lc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ls += __shfl_xor(ls, o, 64);
+    L = L * rescale + ls;
+    acc *= rescale;
+    M = Mn;
+    const int cnt = min(64, p.n_chunks - c0);
+    const float* po = p.part_o + (slot0 + c0) * (32 * 64) + rr * 64 + d;
+    int i = 0;
+    for (; i + 8 <= cnt; i += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = po[(long)(i + u) * (32 * 64)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = fmaf(__shfl(wc, i + u, 64), v[u], acc);
+    }
+    for (; i < cnt; ++i) acc = fmaf(__shfl(wc, i, 64), po[(long)i * (32 * 64)], acc);
   }
   const int q = p.pat.g0 + row;
   T* O = reinterpret_cast<T*>(p.out) + (long)b * p.os[0] + (long)q * p.os[1] + (long)n * p.os[2];
