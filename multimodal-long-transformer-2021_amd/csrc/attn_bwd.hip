@@ -582,15 +582,15 @@ __global__ __launch_bounds__(1024) void drel_reduce_kernel(const BwdParams p) {
     acc += src[id * 64 + d];
     if (d == 0) bs += src[p.Rp * 64 + id];
   }
-  if (part == 0 && p.n_gblk > 0) {                // rows of global tokens (from the combine kernel)
-    for (int b = 0; b < p.B; ++b) {
-      const float* dr = p.drel + (long)(b * p.N + n) * p.pat.ng * p.Rp;
+  if (p.n_gblk > 0) {                             // rows of global tokens (from the combine): dealt over the 16
+    const int pairs = p.B * p.pat.ng;             // parts, so that no part walks a long chain of dependent loads
+#pragma unroll 2
+    for (int gi = part; gi < pairs; gi += 16) {
+      const int b = gi / p.pat.ng, g = gi - b * p.pat.ng;
+      const float x = p.drel[((long)(b * p.N + n) * p.pat.ng + g) * p.Rp + id];
       const T* Q = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)n * p.qs[2];
-      for (int g = 0; g < p.pat.ng; ++g) {
-        const float x = dr[g * p.Rp + id];
-        acc = fmaf(x, (float)Q[(long)(p.pat.g0 + g) * p.qs[1] + d], acc);
-        if (d == 0) bs += x;
-      }
+      acc = fmaf(x, (float)Q[(long)(p.pat.g0 + g) * p.qs[1] + d], acc);
+      if (d == 0) bs += x;
     }
   }
   red[part][d] = acc;
