@@ -138,3 +138,11 @@ def test_qkv_fn_adds_fp32_table_gradients_to_master_params():
   for got, want in ((emb_p.grad, e2.grad), (bias_p.grad, b2.grad)):
     err = float((got / 2 - want.float()).abs().max()) / float(want.float().abs().max())
     assert err < 1e-2, err
+
+
+def test_config3_shape_backward_against_oracle():
+  """BASELINE config 3 shape (S=4096, radius 64, 8 globals, 1-D ids with m=12, bf16), one head: every gradient
+  of the lean backward -- band items, the global-row / global-key chunk partials and their combines riding in
+  the next launches, the per-workgroup dE partials -- against the dense fp64 oracle."""
+  worst = run_bwd(1, 4096, 1, 32, torch.bfloat16, dense=False, radius=64, g0=3971, ng=8, m=12, seed=5)
+  assert worst < 3e-2
