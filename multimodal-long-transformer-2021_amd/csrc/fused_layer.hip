@@ -350,26 +350,39 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ prm, flo
                                                     __bf16* __restrict__ shadow, const float* __restrict__ chunk_wd,
                                                     const float* __restrict__ grad_scale, long n_chunks, AdamwParams a) {
   const float gs = grad_scale ? *grad_scale : 1.f;
-  for (long c = blockIdx.x; c < n_chunks; c += gridDim.x) {
-    const long i = c * 1024 + threadIdx.x * 4;
-    const float decay = 1.f - a.lr * chunk_wd[c];
-    const f32x4 p4 = *reinterpret_cast<const f32x4*>(prm + i), g4 = *reinterpret_cast<const f32x4*>(grd + i);
-    f32x4 a4 = *reinterpret_cast<const f32x4*>(m1 + i), b4 = *reinterpret_cast<const f32x4*>(m2 + i), o4;
-    bf16x4 s4;
+  // two chunks per iteration: eight 16-byte loads in flight per thread before the first store
+  for (long c0 = blockIdx.x; c0 < n_chunks; c0 += 2L * gridDim.x) {
+    const long c1 = c0 + gridDim.x;
+    const bool two = c1 < n_chunks;
+    const long i0 = c0 * 1024 + threadIdx.x * 4, i1 = (two ? c1 : c0) * 1024 + threadIdx.x * 4;
+    const float decay0 = 1.f - a.lr * chunk_wd[c0], decay1 = 1.f - a.lr * chunk_wd[two ? c1 : c0];
+    f32x4 p4[2], g4[2], a4[2], b4[2];
+    p4[0] = *reinterpret_cast<const f32x4*>(prm + i0); g4[0] = *reinterpret_cast<const f32x4*>(grd + i0);
+    a4[0] = *reinterpret_cast<const f32x4*>(m1 + i0); b4[0] = *reinterpret_cast<const f32x4*>(m2 + i0);
+    p4[1] = *reinterpret_cast<const f32x4*>(prm + i1); g4[1] = *reinterpret_cast<const f32x4*>(grd + i1);
+    a4[1] = *reinterpret_cast<const f32x4*>(m1 + i1); b4[1] = *reinterpret_cast<const f32x4*>(m2 + i1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float g = g4[j] * gs;
-      const float mm = a.beta1 * a4[j] + (1.f - a.beta1) * g;
-      const float vv = a.beta2 * b4[j] + (1.f - a.beta2) * g * g;
-      const float denom = sqrtf(vv) * a.inv_sqrt_bc2 + a.eps;
-      const float pn = p4[j] * decay - a.lr * a.inv_bc1 * (mm / denom);
-      a4[j] = mm; b4[j] = vv; o4[j] = pn; s4[j] = (__bf16)pn;
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      const long i = u ? i1 : i0;
+      const float decay = u ? decay1 : decay0;
+      f32x4 o4;
+      bf16x4 s4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g = g4[u][j] * gs;
+        const float mm = a.beta1 * a4[u][j] + (1.f - a.beta1) * g;
+        const float vv = a.beta2 * b4[u][j] + (1.f - a.beta2) * g * g;
+        const float denom = sqrtf(vv) * a.inv_sqrt_bc2 + a.eps;
+        const float pn = p4[u][j] * decay - a.lr * a.inv_bc1 * (mm / denom);
+        a4[u][j] = mm; b4[u][j] = vv; o4[j] = pn; s4[j] = (__bf16)pn;
+      }
+      *reinterpret_cast<f32x4*>(prm + i) = o4;
+      *reinterpret_cast<f32x4*>(m1 + i) = a4[u];
+      *reinterpret_cast<f32x4*>(m2 + i) = b4[u];
+      if (shadow) *reinterpret_cast<bf16x4*>(shadow + i) = s4;
+      if (a.zero_grad) *reinterpret_cast<f32x4*>(grd + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    *reinterpret_cast<f32x4*>(prm + i) = o4;
-    *reinterpret_cast<f32x4*>(m1 + i) = a4;
-    *reinterpret_cast<f32x4*>(m2 + i) = b4;
-    if (shadow) *reinterpret_cast<bf16x4*>(shadow + i) = s4;
-    if (a.zero_grad) *reinterpret_cast<f32x4*>(grd + i) = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 
