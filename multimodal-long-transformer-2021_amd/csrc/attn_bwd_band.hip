@@ -224,9 +224,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     // dS = P o (dP' - delta)
     float ds[16];
     if (p.drop_thresh) {
+      const uint32_t kc = ((uint32_t)(k0 >> 1) + 2u * (uint32_t)h) * kDropPairMul;   // pair index of kap(0, h)
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        const uint32_t hsh = drop_pair_hash(drop_base, (uint32_t)(k0 + kap(i, h)));
+        const uint32_t hsh = drop_pair_finish(drop_base, kc + (uint32_t)(4 * (i >> 2) + ((i & 3) >> 1)) * kDropPairMul);
         const float f0 = (hsh & 0xFFFFu) >= p.drop_thresh ? p.inv_keep : 0.f;
         const float f1 = (hsh >> 16) >= p.drop_thresh ? p.inv_keep : 0.f;
         ds[i] = pr[i] * (dp[i] * f0 - delta);
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
   const int tab_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)tab;
   const uint32_t bn_seed = mix32(p.seed_lo ^ ((uint32_t)bn * 0x9E3779B9u)) + p.seed_hi;
+  const uint32_t drop_kterm = (uint32_t)(k >> 1) * kDropPairMul, drop_ksh = (k & 1) ? 16u : 0u;   // this lane's key
 
   for (int it = 0; it < n_it; ++it) {
     const int q0 = w.at(it) * 32;
@@ -573,8 +575,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       const uint32_t tb = bn_seed + (uint32_t)(q0 + h4) * 0x85EBCA6Bu;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const uint32_t bits = drop_bits16(tb + (uint32_t)((i & 3) + 8 * (i >> 2)) * 0x85EBCA6Bu, (uint32_t)k);
-        const float df = bits >= p.drop_thresh ? p.inv_keep : 0.f;
+        const uint32_t hsh = drop_pair_finish(tb + (uint32_t)((i & 3) + 8 * (i >> 2)) * 0x85EBCA6Bu, drop_kterm);
+        const float df = ((hsh >> drop_ksh) & 0xFFFFu) >= p.drop_thresh ? p.inv_keep : 0.f;
         g[i] = pr[i] * (dp[i] * df - rowc[32 + (i & 3) + 8 * (i >> 2) + h4]);
         pr[i] *= df;
       }

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) void attn_rows_combine_kernel(const FwdParams p
   }
   const int q = p.pat.g0 + row;
   T* O = reinterpret_cast<T*>(p.out) + (long)b * p.os[0] + (long)q * p.os[1] + (long)n * p.os[2];
-  O[d] = (T)(acc / L);
+  O[d] = (T)(acc * p.part_scale / L);
   if (p.lse && d == 0) p.lse[((long)b * p.N + n) * p.S + q] = (M + log2f(L)) * kLn2;
 }
 

@@ -240,13 +240,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
     for (int i = 0; i < 16; ++i) psum += pr[i];
     l_run += psum;
 
-    if (p.drop_thresh) {                   // 16 bits per element, one mix per key pair
+    if (p.drop_thresh) {                   // 16 bits per element, one hash per key pair; 1 / keep in the epilogue
       const uint32_t t16 = p.drop_thresh;
+      const uint32_t kc = ((uint32_t)(k0 >> 1) + 2u * (uint32_t)h) * kDropPairMul;   // pair index of kap(0, h)
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        const uint32_t hsh = drop_pair_hash(drop_base, (uint32_t)(k0 + kap(i, h)));   // k even
-        pr[i] = (hsh & 0xFFFFu) >= t16 ? pr[i] * p.inv_keep : 0.f;
-        pr[i + 1] = (hsh >> 16) >= t16 ? pr[i + 1] * p.inv_keep : 0.f;
+        const uint32_t hsh = drop_pair_finish(drop_base, kc + (uint32_t)(4 * (i >> 2) + ((i & 3) >> 1)) * kDropPairMul);
+        pr[i] = (hsh & 0xFFFFu) >= t16 ? pr[i] : 0.f;
+        pr[i + 1] = (hsh >> 16) >= t16 ? pr[i + 1] : 0.f;
       }
     }
     mma_xt(o0, o1, VTile<T>{}, vlds, pr, lane);   // O^T[d x q] += V^T[d x key] . P^T[key x q]
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
   }
   if (!q_ok) return;
   if (p.skip_global_rows && is_global(p.pat, q)) return;
-  const float inv = 1.f / l_tot;
+  const float inv = (p.drop_thresh ? p.inv_keep : 1.f) / l_tot;
   T* O = reinterpret_cast<T*>(p.out) + (long)b * p.os[0] + (long)q * p.os[1] + (long)n * p.os[2];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {

@@ -27,6 +27,7 @@ struct FwdParams {
   // kRows
   float* part_o;
   float* part_ml;
+  float part_scale;   // combine: factor on the summed partial rows (1 / keep when the lean kernel left it to the epilogue)
   int n_chunks, chunk_tiles, n_rowblk;
   int n_band_blocks;  // B*N*ceil(S/128): blocks before the global-row items
   int perm_1d;        // 1-D ids with R >= 2m+1: table columns permuted, fast path allowed

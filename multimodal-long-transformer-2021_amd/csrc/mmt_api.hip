@@ -174,6 +174,7 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     p.part_ml = p.part_o + (size_t)desc->B * desc->N * pl.n_rowblk * pl.n_chunks * (32 * 64);
   }
   const bool lean = bf16 && (p.pat.id_mode == 0 || p.perm_1d);   // attn_fwd_band.hip
+  p.part_scale = (lean && p.drop_thresh) ? p.inv_keep : 1.f;
   e = lean ? mmt::launch_attn_fwd_band_bf16(p, st) : mmt::launch_attn_fwd(p, mmt::kBand, bf16, st);
   if (e != hipSuccess) return fail(MMT_E_LAUNCH, "band forward launch: %s", hipGetErrorString(e));
   if (pl.split_rows) {

@@ -96,14 +96,25 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-// Attention-probability dropout: 16 random bits per (b*N+n, q, k); one 32-bit mix serves the
-// key pair (k & ~1, k | 1).  keep iff bits >= thresh16.
+// Attention-probability dropout: 16 random bits per (b*N+n, q, k); one hash serves the key pair
+// (k & ~1, k | 1); keep iff bits >= thresh16 (restated in oracle/attention.py: dropout_keep_mask).
+// The row base is a full mix32; the per-pair finalizer is ONE multiply round (x ^= x>>16, x *= M, x ^= x>>15):
+// the pair term is already a product with a large odd constant, and the keep-mask statistics (keep rate, row /
+// column spread, neighbour correlations < 0.003) match the two-round mixer's.  The hash is the biggest single
+// item of a one-id tile's VALU work, and its 32-bit multiplies run at a quarter of the full rate.
+constexpr uint32_t kDropPairMul = 0xC2B2AE35u;
 __host__ __device__ __forceinline__ uint32_t drop_row_base(uint32_t seed_lo, uint32_t seed_hi,
                                                            uint32_t bn, uint32_t q) {
   return mix32(seed_lo ^ (bn * 0x9E3779B9u)) + seed_hi + q * 0x85EBCA6Bu;
 }
+// `pair_term` = (k >> 1) * kDropPairMul (the kernels build it with one multiply per tile plus constants)
+__host__ __device__ __forceinline__ uint32_t drop_pair_finish(uint32_t row_base, uint32_t pair_term) {
+  uint32_t x = row_base ^ pair_term;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+  return x;
+}
 __host__ __device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row_base, uint32_t k) {
-  return mix32(row_base ^ ((k >> 1) * 0xC2B2AE35u));
+  return drop_pair_finish(row_base, (k >> 1) * kDropPairMul);
 }
 __host__ __device__ __forceinline__ uint32_t drop_bits16(uint32_t row_base, uint32_t k) {
   const uint32_t hsh = drop_pair_hash(row_base, k);

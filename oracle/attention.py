@@ -156,3 +156,35 @@ def relative_attention_bwd(dout, q, k, v, rel_emb=None, rel_bias=None, att_mask=
         drel_bias += np.transpose(drelall.sum(axis=1), (1, 0))
     dq[b] = np.transpose(dqb, (1, 0, 2)); dk[b] = np.transpose(dkb, (1, 0, 2))
   return dict(dq=dq, dk=dk, dv=dv, drel_emb=drel_emb, drel_bias=drel_bias)
+
+
+# ---- attention-probability dropout: the keep mask the HIP kernels generate in-kernel ---------------------------
+# Restates csrc/mmt_common.h (mix32, drop_row_base, drop_pair_finish, drop_bits16) and the parameter derivation of
+# csrc/mmt_api.hip (16-bit threshold, exact keep probability).  The reference draws its mask from TF's stateless
+# RNG (tf.nn.dropout inside QkvRelativeAttention, etc_layers/attention.py); no two frameworks share that stream, so
+# the contract here is: this mask, exactly, in the forward and in both backward kernels.
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def _mix32(x):
+  x = x & _M32
+  x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & _M32
+  x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & _M32
+  x ^= x >> np.uint64(16)
+  return x
+
+
+def dropout_keep_mask(B: int, N: int, S: int, p: float, seed: int):
+  """(keep [B,N,S,S] bool, keep_prob) for attention dropout probability p and the 64-bit seed."""
+  t = int(p * 65536.0 + 0.5)
+  t = 1 if t < 1 else (65535 if t > 65535 else t)
+  seed_lo, seed_hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+  bn = np.arange(B * N, dtype=np.uint64).reshape(B * N, 1, 1)
+  q = np.arange(S, dtype=np.uint64).reshape(1, S, 1)
+  k = np.arange(S, dtype=np.uint64).reshape(1, 1, S)
+  row_base = (_mix32(seed_lo ^ ((bn * np.uint64(0x9E3779B9)) & _M32)) + seed_hi + q * np.uint64(0x85EBCA6B)) & _M32
+  x = row_base ^ (((k >> np.uint64(1)) * np.uint64(0xC2B2AE35)) & _M32)
+  x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & _M32; x ^= x >> np.uint64(15)
+  bits = np.where((k & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
+  keep = (bits >= np.uint64(t)).reshape(B, N, S, S)
+  return keep, (65536.0 - t) / 65536.0

@@ -146,3 +146,40 @@ def test_config3_shape_backward_against_oracle():
   the next launches, the per-workgroup dE partials -- against the dense fp64 oracle."""
   worst = run_bwd(1, 4096, 1, 32, torch.bfloat16, dense=False, radius=64, g0=3971, ng=8, m=12, seed=5)
   assert worst < 3e-2
+
+
+# ---- attention-probability dropout: the in-kernel keep mask against its restatement (oracle.dropout_keep_mask) ----
+@pytest.mark.parametrize('path', ['lean_bf16', 'general_f32', 'dense_f32'])
+def test_dropout_mask_matches_oracle_forward_and_backward(path):
+  """With the restated keep mask handed to the oracle, outputs and every gradient agree as without dropout: the
+  forward and the two backward kernels of each path regenerate exactly that mask."""
+  import mmt_amd
+  B, S, N, R, m = 2, 320, 2, 32, 12
+  pdrop, seed = 0.25, 0x1234_5678_9ABC_DEF1
+  dtype = torch.bfloat16 if path == 'lean_bf16' else torch.float32
+  q, k, v, emb, bias = attention_inputs(B, S, N, R, 3)
+  dout = np.random.default_rng(9).standard_normal(q.shape).astype(np.float32)
+  if dtype == torch.bfloat16:
+    q, k, v, emb, bias, dout = (bf16_round(x) for x in (q, k, v, emb, bias, dout))
+  g0, ng, radius = 300, 8, 64
+  mask, ids = dense_side_inputs(B, S, None, radius, g0, ng, 1, m)
+  keep, keep_prob = oa.dropout_keep_mask(B, N, S, pdrop, seed)
+  assert abs(keep.mean() - 0.75) < 0.01
+  ref_o, _ = oa.relative_attention_fwd(q, k, v, emb, bias, mask, ids, keep_mask=keep, keep_prob=keep_prob, dtype=np.float64)
+  ref = oa.relative_attention_bwd(dout, q, k, v, emb, bias, mask, ids, keep_mask=keep, keep_prob=keep_prob)
+  dev = lambda x, dt=dtype: torch.from_numpy(x).cuda().to(dt).contiguous()
+  tq, tk, tv, te, tb = (dev(x).requires_grad_(True) for x in (q, k, v, emb, bias))
+  kw = dict(dropout_p=pdrop, dropout_seed=seed)
+  if path == 'dense_f32':
+    out = mmt_amd.relative_attention(tq, tk, tv, te, tb, att_mask=dev(mask, torch.int32), relative_att_ids=dev(ids, torch.int32), **kw)
+  else:
+    pat = mmt_amd.AttentionPattern(local_radius=radius, global_start=g0, n_global=ng, id_mode=1, max_dist=m)
+    out = mmt_amd.relative_attention(tq, tk, tv, te, tb, pattern=pat, **kw)
+  out.backward(dev(dout))
+  tol = 3e-2 if dtype == torch.bfloat16 else 2e-3
+  err = np.abs(out.detach().float().cpu().numpy() - ref_o).max()
+  assert err < tol, f'out: {err}'
+  for name, t in (('dq', tq), ('dk', tk), ('dv', tv), ('drel_emb', te), ('drel_bias', tb)):
+    got, want = t.grad.float().cpu().numpy(), ref[name]
+    err = np.abs(got - want).max() / (max(1.0, np.abs(want).max()) if dtype == torch.bfloat16 else 1.0)
+    assert err < tol, f'{name}: {err}'
