@@ -97,10 +97,14 @@ __device__ __forceinline__ void half_pair(float x, float& a, float& b) {
 __device__ __forceinline__ float half_max(float x) { float a, b; half_pair(x, a, b); return fmaxf(a, b); }
 __device__ __forceinline__ float half_sum(float x) { float a, b; half_pair(x, a, b); return a + b; }
 
-constexpr int kTStride(int Rp) { return Rp + 1; }
+// Row stride of the per-wave relative-score tables (floats).  Two access shapes matter: a column read by
+// 32 lanes (address r * stride + c) and the DIAGONAL gather of a mixed-id tile, where lane r reads column
+// c - r (address r * (stride - 1) + c).  Rp + 1 made the second a 32-way bank conflict (32 r + c hits two
+// banks); with Rp + 2 the first walks 34 r (32 distinct even banks) and the second 33 r (all distinct).
+constexpr int kTStride(int Rp) { return Rp + 2; }
 constexpr float kRescaleThr = 6.0f;
 
-// LDS carve per wave: T table [32][Rp+1] f32, then (bf16 only) V tile 32 x 128 B.
+// LDS carve per wave: T table [32][kTStride] f32, then (bf16 only) V tile 32 x 128 B.
 template <typename T, int Rp> struct WaveLds {
   static constexpr int kTBytes = 32 * kTStride(Rp) * 4;
   static constexpr int kTBytesAligned = (kTBytes + 15) & ~15;
