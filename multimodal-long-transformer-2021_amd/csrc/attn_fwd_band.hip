@@ -200,6 +200,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
         const unsigned dd = (unsigned)(dbase + (i & 3) + 8 * (i >> 2) + W);
         s2[i] = fmaf(c[i], p.sscale, relc) + (dd <= W2 ? 0.f : p.mask_add);
       }
+    } else if (in_range && seg_all && one_id && !ignore_band && (dmin > W || dmax < -W)) {   // ---- class G
+      // a tile that lies wholly outside the band: only its global keys are visible (every band wave meets one)
+      const unsigned gb = (unsigned)(k0 + 4 * h - p.pat.g0), ng = (unsigned)p.pat.ng;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        s2[i] = fmaf(c[i], p.sscale, relc) + (gb + (unsigned)((i & 3) + 8 * (i >> 2)) < ng ? 0.f : p.mask_add);
     } else {                                                   // ---- class C (general)
       const int kb = k0 + 4 * h;
       const bool qv = q < valid_len;
