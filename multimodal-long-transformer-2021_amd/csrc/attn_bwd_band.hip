@@ -202,6 +202,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
         const unsigned dd = (unsigned)(dbase + (i & 3) + 8 * (i >> 2) + W);
         pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rc) + (dd <= W2 ? 0.f : p.mask_add));
       }
+    } else if (tc.outside && one_id) {                          // class G: only the tile's global keys are visible
+      const unsigned gb = (unsigned)(k0 + 4 * h - p.pat.g0), ng = (unsigned)p.pat.ng;
+      const float rc = relc - lse2;
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rc) + (gb + (unsigned)((i & 3) + 8 * (i >> 2)) < ng ? 0.f : p.mask_add));
     } else {                                                    // class C
       const int kb = k0 + 4 * h;
       const bool qv = q < valid_len;
@@ -549,6 +555,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
         const float rl = HAS_REL ? relrow[row] : -rowc[row];
         const unsigned dd = (unsigned)(dbase - ci + W);
         pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rl) + (dd <= W2 ? 0.f : p.mask_add));
+      }
+    } else if (tc.outside && one_id) {                    // class G: only the tile's global query rows see these keys
+      const unsigned gb = (unsigned)(q0 + h4 - p.pat.g0), ng = (unsigned)p.pat.ng;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ci = (i & 3) + 8 * (i >> 2), row = ci + h4;
+        const float rl = HAS_REL ? relrow[row] : -rowc[row];
+        pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rl) + (gb + (unsigned)ci < ng ? 0.f : p.mask_add));
       }
     } else {                                              // class C
       const bool kv = k < valid_len;

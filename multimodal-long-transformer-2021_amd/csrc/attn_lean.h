@@ -67,6 +67,7 @@ struct TileClass {
   bool edge;       // only the |d| <= W test can mask a pair (no pad boundary, no global keys/rows)
   bool far_neg;    // d <= -m for every pair  (clipped column 0)
   bool far_pos;    // d >=  m for every pair  (clipped column 2m)
+  bool outside;    // the tile lies wholly outside the band: only global keys (rows) of it are visible
 };
 __device__ __forceinline__ TileClass classify_tile(int q0, int k0, int S, int valid_len, int W, int m,
                                                    bool ignore_band, bool no_global_in_tile) {
@@ -79,6 +80,7 @@ __device__ __forceinline__ TileClass classify_tile(int q0, int k0, int S, int va
   t.edge = in_range && seg_all && no_global_in_tile && !ignore_band;
   t.far_neg = dmax <= -m;
   t.far_pos = dmin >= m;
+  t.outside = in_range && seg_all && !ignore_band && (dmin > W || dmax < -W);
   return t;
 }
 
