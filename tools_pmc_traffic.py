@@ -23,7 +23,7 @@ out = {
             'streaming reads, WRITE_SIZE as is; unit KB',
   'hbm_bytes_per_launch': int((2 * fetch + write) * 1024),
   'algorithmic_bytes_per_launch': 101649408,
-  'note': 're-measured at round-1 v13; all_kernels_raw_KB = per-launch means of every attention kernel of one forward+backward call',
+  'note': 're-measured at round-1 v15; all_kernels_raw_KB = per-launch means of every attention kernel of one forward+backward call',
   'all_kernels_raw_KB': {k: {'FETCH_SIZE': round(f[k], 1), 'WRITE_SIZE': round(w.get(k, 0.0), 1)} for k in f},
 }
 json.dump(out, open('profiles/attn_fwd_traffic.json', 'w'), indent=1)
