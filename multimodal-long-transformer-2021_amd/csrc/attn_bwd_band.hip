@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   if (HAS_REL) {
     float* bias_ts = reinterpret_cast<float*>(xlds);
     if (lane < Rp)
-      bias_ts[lane] = (p.bias && lane < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)lane * p.N + n] * p.tscale : 0.f;
+      bias_ts[lane] = (p.bias && icol(m, lane) < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)icol(m, lane) * p.N + n] * p.tscale : 0.f;   // by column
     const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
     const unsigned es1b = (unsigned)p.N * 128;
     const auto re = make_rsrc(Eb, (unsigned)(p.R - 1) * es1b + 128);
@@ -134,13 +134,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     for (int rb = 0; rb < Rp / 32; ++rb) {
       Frag<T> ef;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) ef.v[s] = buf16(re, (unsigned)r * es1b + 64 * h + 16 * s, (unsigned)(rb * 32) * es1b);
+      for (int s = 0; s < 4; ++s) ef.v[s] = buf16(re, (unsigned)icol(m, rb * 32 + r) * es1b + 64 * h + 16 * s, 0u);   // row r <- id of column rb*32 + r
       f32x16 c = {0};
       c = mma_rows(ef, qf, c);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int id = rb * 32 + kap(i, h);
-        tab[r * kTStride(Rp) + tcol(1, m, id)] = fmaf(c[i], p.tscale, bias_ts[id]);
+        const int col = rb * 32 + kap(i, h);
+        tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bias_ts[col]);
       }
     }
     wave_lds_sync();
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   const auto re = make_rsrc(HAS_REL ? (const void*)Eb : (const void*)Qb, HAS_REL ? (unsigned)(p.R - 1) * es1b + 128 : 0u);
   if (HAS_REL) {
     if (lane < Rp)
-      bias_ts[lane] = (p.bias && lane < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)lane * p.N + n] * p.tscale : 0.f;
+      bias_ts[lane] = (p.bias && icol(m, lane) < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)icol(m, lane) * p.N + n] * p.tscale : 0.f;   // by column
   }
   wave_lds_sync();
 
@@ -510,13 +510,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       for (int rb = 0; rb < Rp / 32; ++rb) {
         Frag<T> ef;                     // E rows: L2-resident, only the mixed-id tiles need them
 #pragma unroll
-        for (int s = 0; s < 4; ++s) ef.v[s] = buf16(re, (unsigned)r * es1b + 64 * h + 16 * s, (unsigned)(rb * 32) * es1b);
+        for (int s = 0; s < 4; ++s) ef.v[s] = buf16(re, (unsigned)icol(m, rb * 32 + r) * es1b + 64 * h + 16 * s, 0u);   // row r <- id of column rb*32 + r
         f32x16 c = {0};
         c = mma_rows(ef, qf, c);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-          const int id = rb * 32 + (i & 3) + 8 * (i >> 2) + h4;
-          tab[r * kTStride(Rp) + tcol(1, m, id)] = fmaf(c[i], p.tscale, bias_ts[id]) + nl;
+          const int col = rb * 32 + (i & 3) + 8 * (i >> 2) + h4;
+          tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bias_ts[col]) + nl;
         }
       }
       wave_lds_sync();

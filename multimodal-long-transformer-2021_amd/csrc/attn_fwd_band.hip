@@ -115,10 +115,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
 #pragma unroll
     for (int rb = 0; rb < Rp / 32; ++rb)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) ef[rb].v[s] = buf16(re, (unsigned)r * es1b + 64 * h + 16 * s, (unsigned)(rb * 32) * es1b);
+      for (int s = 0; s < 4; ++s) ef[rb].v[s] = buf16(re, (unsigned)icol(m, rb * 32 + r) * es1b + 64 * h + 16 * s, 0u);   // row r <- id of column rb*32 + r
     float* bias_ts = reinterpret_cast<float*>(vlds);
     if (lane < Rp)
-      bias_ts[lane] = (p.bias && lane < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)lane * p.N + n] * p.tscale : 0.f;
+      bias_ts[lane] = (p.bias && icol(m, lane) < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)icol(m, lane) * p.N + n] * p.tscale : 0.f;   // by column
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
       c = mma_rows(ef[rb], qf, c);   // [id x q]
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int id = rb * 32 + kap(i, h);
-        tab[r * kTStride(Rp) + tcol(1, m, id)] = fmaf(c[i], p.tscale, bias_ts[id]);
+        const int col = rb * 32 + kap(i, h);
+        tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bias_ts[col]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

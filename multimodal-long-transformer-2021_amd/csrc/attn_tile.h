@@ -119,6 +119,12 @@ __device__ __forceinline__ int tcol(int perm_1d, int m, int id) {
   const int pc = id <= m ? m + id : 2 * m - id;
   return ((perm_1d != 0) & (id <= 2 * m)) ? pc : id;
 }
+// Inverse of tcol for the permuted (1-D) layout: the relative id whose score lives in table column c.  The lean
+// kernels load E row icol(m, r) into fragment row r, so that the table product comes out in COLUMN order and is
+// stored without a per-element tcol().
+__device__ __forceinline__ int icol(int m, int c) {
+  return c > 2 * m ? c : (c >= m ? c - m : 2 * m - c);
+}
 
 
 // acc^T[d x col] += X^T[d x row] . vals[row x col] for a 32-row tile X staged as a VTile:
