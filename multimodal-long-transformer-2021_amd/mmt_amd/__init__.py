@@ -10,7 +10,7 @@ from .ops import (AttentionPattern, relative_attention, relative_attention_backw
 from .encoder import MmtEncoder
 from .models import MmtClassificationModel, MmtPretrainingModel
 from .benchmarks import make_train_step_bench
-from . import configs, distribute, input_utils, layers, optimization, registry_imports, tasks
+from . import configs, distribute, fused, input_utils, layers, optimization, registry_imports, tasks
 
 __all__ = ['MmtEncoder', 'MmtPretrainingModel', 'MmtClassificationModel', 'make_train_step_bench',
            'configs', 'tasks', 'distribute', 'optimization', 'layers', 'input_utils',

@@ -91,7 +91,6 @@ class MmtEncoder(nn.Module):
         'use_one_hot_lookup': use_one_hot_lookup, 'use_pooler_layer': use_pooler_layer,
     }
     self._config = collections.namedtuple('Config', config_dict.keys())(**config_dict)
-    self._step = 0
     self.use_fused_embedding = True
 
   def _fused_embed_ok(self, word_ids):
@@ -121,7 +120,7 @@ class MmtEncoder(nn.Module):
       return fused.embed_assemble(word_ids, segment_ids, self._word_embedding_layer.embedding_table,
                                   self._segment_embedding_layer.embedding_table, ln.weight, ln.bias,
                                   pos_table=self._position_embeddings, patch_proj=pe, eps=ln.eps, p=p,
-                                  seed=fused.next_seed(self._step) if p else 0, patch_start=2, out_dtype=cd)
+                                  seed=fused.next_seed(0) if p else 0, patch_start=2, out_dtype=cd)
     word = self._word_embedding_layer(word_ids)
     seg = self._segment_embedding_layer(segment_ids)
     word = F.layer_norm(word, ln.normalized_shape, ln.weight, ln.bias, ln.eps)
@@ -143,10 +142,9 @@ class MmtEncoder(nn.Module):
               attention_pattern: Optional[AttentionPattern] = None, valid_len=None):
     training = bool(training)
     emb = self.embed(word_ids, segment_ids, patch_embeddings, training).to(self.compute_dtype)
-    self._step += 1
     out = self._transformer_layers(inputs=emb, att_mask=att_mask, relative_att_ids=relative_att_ids,
-                                   training=training, pattern=attention_pattern,
-                                   valid_len=valid_len, dropout_seed=self._step)
+                                   training=training, pattern=attention_pattern, valid_len=valid_len,
+                                   dropout_seed=(fused.next_seed(0) >> 24) if training else 0)
     outputs = {'sequence_output': out}
     if hasattr(self, '_pooler_weight'):
       first = out[:, 0]

@@ -7,7 +7,6 @@ and their gradients come back fp32 straight from the kernels.
 """
 from __future__ import annotations
 
-import itertools
 import os
 
 from typing import Optional
@@ -16,13 +15,26 @@ import torch
 
 from . import _lib
 
-_seed_counter = itertools.count(1)
+# Dropout seeds are a pure function of (train step, micro step, data-parallel rank, index of the
+# dropout site within the forward pass): replicas draw different masks for their shards and a run
+# resumed from a checkpoint continues with the masks the uninterrupted run would have drawn.  Code that
+# never calls `set_seed_stream` (plain `model(...)` calls) just keeps counting from where it is.
+_seed_state = {'base': 0, 'n': 0}
+
+
+def set_seed_stream(step: int, micro_step: int = 0, rank: int = 0) -> None:
+  """Called by the tasks' train_step before every micro-step's forward pass."""
+  _seed_state['base'] = ((int(step) * 0x9E3779B97F4A7C15) ^ (int(micro_step) * 0xC2B2AE3D27D4EB4F)
+                         ^ ((int(rank) + 1) * 0x165667B19E3779F9)) & ((1 << 63) - 1)
+  _seed_state['n'] = 0
 
 
 def next_seed(base: int = 0) -> int:
   # 63 bits: the seed travels through autograd.Function.apply as a Python int, which torch's
   # shape-recording profiler converts to int64
-  return (int(base) * 0x9E3779B97F4A7C15 + next(_seed_counter) * 0xD1B54A32D192ED03) & ((1 << 63) - 1)
+  _seed_state['n'] += 1
+  return (_seed_state['base'] + int(base) * 0x9E3779B97F4A7C15
+          + _seed_state['n'] * 0xD1B54A32D192ED03) & ((1 << 63) - 1)
 
 
 def _desc(x2d: torch.Tensor, eps=1e-12, p=0.0, seed=0) -> _lib.RowsDesc:
@@ -111,7 +123,7 @@ class _LayerNormFn(torch.autograd.Function):
       dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
     d = _desc(x2, ctx.eps)
     d.accumulate = int(direct)
-    d.defer_reduce = int(side_stream_ok(gamma_p, beta_p))
+    d.defer_reduce = int(direct and side_stream_ok(gamma_p, beta_p))
     ws = _ws(d, x2)
     with torch.cuda.device(x2.device):
       _lib.check(_lib.lib().mmt_ln_bwd(d, _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg),
@@ -174,7 +186,7 @@ class _ResidualBlockFn(torch.autograd.Function):
       db = torch.empty_like(gamma) if has_ln else None
     d = _desc(x_new, eps, p, seed)
     d.accumulate = int(direct)
-    d.defer_reduce = int(side_stream_ok(bias_p, gamma_p, beta_p))
+    d.defer_reduce = int(direct and side_stream_ok(bias_p, gamma_p, beta_p))
     ws = _ws(d, x_new)
     with torch.cuda.device(x_new.device):
       _lib.check(_lib.lib().mmt_residual_block_bwd(
@@ -217,7 +229,7 @@ class _BiasGeluFn(torch.autograd.Function):
     dbias, direct = _grad_target(ctx.param, bias)
     d = _desc(u2)
     d.accumulate = int(direct)
-    d.defer_reduce = int(side_stream_ok(ctx.param))
+    d.defer_reduce = int(direct and side_stream_ok(ctx.param))
     ws = _ws(d, u2)
     with torch.cuda.device(u2.device):
       _lib.check(_lib.lib().mmt_bias_gelu_bwd(d, _p(dy2), _p(u2), _p(bias), _p(du), _p(dbias), _p(ws),
@@ -331,7 +343,7 @@ def wgrad_accumulate_(dw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, dbias
 _SIDE_MODE = int(os.environ.get('MMT_WGRAD_SIDE_STREAM', '1'))
 WGRAD_SIDE_STREAM = _SIDE_MODE != 0
 _SIDE = {}
-_side_pending = set()
+_side_pending = {}         # device -> id of the backward pass (graph task) whose end-of-backward join is queued
 
 
 def _side_stream(device):
@@ -357,6 +369,11 @@ def _join_side_streams():
   for device in list(_side_pending):
     torch.cuda.current_stream(device).wait_stream(_SIDE[device])
   _side_pending.clear()
+
+
+def _graph_task_id():
+  fn = getattr(torch._C, '_current_graph_task_id', None)
+  return fn() if fn is not None else -1
 
 
 def side_stream_ok(*params) -> bool:
@@ -385,8 +402,11 @@ def wgrad_accumulate_side_(dw, dy, x, dbias=None) -> bool:
 
 
 def _mark_side(device):
-  if device not in _side_pending:
-    _side_pending.add(device)
+  # one join per backward pass: keyed by the engine's graph-task id, so a backward that raised before its
+  # callbacks ran (entry left behind) cannot keep a later backward from queueing its own join
+  gid = _graph_task_id()
+  if _side_pending.get(device, None) != gid or gid == -1:
+    _side_pending[device] = gid
     torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
 
 

@@ -40,6 +40,21 @@ def get_activation(name_or_fn) -> Optional[Callable]:
   return table[name_or_fn]
 
 
+def _current_shadow(param: torch.Tensor, dtype: torch.dtype):
+  """The low-precision copy `optimization.FusedAdamW` keeps next to a master parameter, or None.  The
+  optimizer's kernel updates master and shadow together without touching torch's version counter; any
+  OTHER in-place write to the master (load_state_dict, checkpoint restore, manual init -- all bump
+  `param._version`) is noticed here and the shadow is re-synchronised before it is used."""
+  shadow = getattr(param, '_mmt_shadow', None)
+  if shadow is None or shadow.dtype != dtype:
+    return None
+  if param._version != getattr(param, '_mmt_shadow_version', param._version):
+    with torch.no_grad():
+      shadow.copy_(param.detach())
+    param._mmt_shadow_version = param._version
+  return shadow
+
+
 class _CastParamFn(torch.autograd.Function):
   """fp32 master parameter -> compute dtype.  The backward accumulates the low-precision
   gradient straight into `param.grad` (one mixed-precision add instead of a cast kernel plus an
@@ -48,10 +63,8 @@ class _CastParamFn(torch.autograd.Function):
   @staticmethod
   def forward(ctx, param, dtype):
     ctx.param = param
-    shadow = getattr(param, '_mmt_shadow', None)      # kept current by optimization.FusedAdamW
-    if shadow is not None and shadow.dtype == dtype:
-      return shadow
-    return param.detach().to(dtype)
+    shadow = _current_shadow(param, dtype)
+    return shadow if shadow is not None else param.detach().to(dtype)
 
   @staticmethod
   def backward(ctx, g):
@@ -78,8 +91,8 @@ _FFN_FWD_FUSED = os.environ.get('MMT_FFN_FWD_FUSED', '0') != '0'
 
 
 def _param_weight(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
-  shadow = getattr(param, '_mmt_shadow', None)
-  return shadow if (shadow is not None and shadow.dtype == dtype) else param.detach().to(dtype)
+  shadow = _current_shadow(param, dtype)
+  return shadow if shadow is not None else param.detach().to(dtype)
 
 
 def _notify(param):
@@ -283,7 +296,6 @@ class RelativeAttention(nn.Module):
         self.relative_bias_table = None
     else:
       self.relative_emb_table = self.relative_bias_table = None
-    self._calls = 0
 
   def forward(self, x, att_mask=None, relative_att_ids=None, pattern=None, valid_len=None,
               training=False, dropout_seed=0, add_output_bias=True):
@@ -302,12 +314,11 @@ class RelativeAttention(nn.Module):
       emb = cast_param(emb_p, x.dtype)
       bias = None if bias_p is None else cast_param(bias_p, x.dtype)
       sinks = None
-    self._calls += 1
     p_drop = self.att_dropout_prob if training else 0.0
     out = ops.relative_attention_qkv(
         qkv, emb, bias, rel_grad_sinks=sinks, att_mask=att_mask, relative_att_ids=relative_att_ids,
         pattern=pattern, valid_len=valid_len, dropout_p=p_drop,
-        dropout_seed=(int(dropout_seed) * 1000003 + self._calls) if p_drop > 0 else 0)
+        dropout_seed=int(dropout_seed) if p_drop > 0 else 0)
     return _linear(out.reshape(B, S, H), self.output_weight, self.output_bias if add_output_bias else None)
 
 

@@ -59,6 +59,8 @@ class FusedAdamW:
       p._mmt_shadow = slab['shadow'][off:off + k].view_as(p)
     for slab in self.slabs:
       slab['shadow'].copy_(slab['param'])
+    for p, _, _ in reducer.layout:
+      p._mmt_shadow_version = p._version     # layers._current_shadow re-syncs after any later torch-side write
 
   def zero_grad(self, set_to_none: bool = False):
     self.reducer.zero_grad()
@@ -82,6 +84,8 @@ class FusedAdamW:
     (checkpoint restore, manual initialisation)."""
     for slab in self.slabs:
       slab['shadow'].copy_(slab['param'])
+    for p, _, _ in self.reducer.layout:
+      p._mmt_shadow_version = p._version
 
   @torch.no_grad()
   def step(self, grad_scale=None):

@@ -9,7 +9,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import configs, gemm_tuning, input_utils, layers, models
+from . import configs, fused, gemm_tuning, input_utils, layers, models
 
 _TASKS = {}
 
@@ -27,6 +27,20 @@ def get_task(task_config, logging_dir=None, **kw):
     if type(task_config) is cfg_cls:
       return task_cls(task_config, logging_dir=logging_dir, **kw)
   raise KeyError(f'no task registered for {type(task_config).__name__}')
+
+
+def gradient_reduce_mode(task_config) -> str:
+  """How the data-parallel reducer combines per-replica gradients for a task config.
+
+  The reference's optimizer SUMs the replicas' gradients (`pretraining.py:273`).  With
+  `scale_loss=True` each replica differentiates `loss / num_replicas` (`pretraining.py:286-296`), so
+  the SUM is the mean-of-replicas gradient: 'sum'.  With the default `scale_loss=False` the reference
+  applies world x the mean; this build averages instead ('mean') unless
+  MMT_REFERENCE_SUM=1 asks for the reference's literal behaviour."""
+  import os
+  if getattr(task_config, 'scale_loss', False):
+    return 'sum'
+  return 'sum' if os.environ.get('MMT_REFERENCE_SUM') else 'mean'
 
 
 def _compute_dtype(runtime_dtype: Optional[str]) -> torch.dtype:
@@ -66,8 +80,15 @@ class _TaskBase:
 
   # ---- the reference's gradient-accumulation train step (pretraining.py:224-298) ----------
   def train_step(self, inputs, model, optimizer, metrics: Optional[Dict] = None, reducer=None,
-                 micro_batch_size: Optional[int] = None, clip_norm: Optional[float] = None):
+                 micro_batch_size: Optional[int] = None, clip_norm: Optional[float] = None,
+                 step: Optional[int] = None):
+    """`step` = global train step (from the trainer loop / checkpoint): with the micro-step index and
+    the data-parallel rank it determines every dropout mask of this call (`fused.set_seed_stream`)."""
     inputs, labels = inputs
+    if step is None:
+      step = self._auto_step = getattr(self, '_auto_step', 0) + 1
+    rank = torch.distributed.get_rank() if (torch.distributed.is_available() and
+                                            torch.distributed.is_initialized()) else 0
     micro = micro_batch_size or getattr(self.task_config, 'micro_batch_size', None)
     batch_size = inputs['word_ids'].shape[0]
     micro = micro or batch_size
@@ -85,6 +106,7 @@ class _TaskBase:
       # the reference takes the leading `micro` examples, then rotates them to the end
       if reducer is not None:
         reducer.set_armed(i == num_small_steps - 1)
+      fused.set_seed_stream(step, i, rank)
       sl = slice(i * micro, (i + 1) * micro)
       small_inputs = {k: (v[sl] if is_t(v) else v) for k, v in inputs.items()}
       small_labels = {k: v[sl] for k, v in labels.items()}

@@ -33,8 +33,7 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
   model = task.build_model().to(device)
   task.initialize(model)              # warm start from task.init_checkpoint (no-op when empty)
   opt_cfg = params.trainer.optimizer_config
-  reducer = strategy.make_reducer(list(model.parameters()),
-                                  reduce='sum' if not params.task.scale_loss and os.environ.get('MMT_REFERENCE_SUM') else 'mean')
+  reducer = strategy.make_reducer(list(model.parameters()), reduce=tasks.gradient_reduce_mode(params.task))
   optimizer = optimization.create_optimizer(model, opt_cfg, reducer=reducer)
   data = task.build_inputs(params.task.train_data, device=device, rank=strategy.rank)
   steps = max_steps or params.trainer.train_steps
@@ -58,7 +57,7 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
     for step in range(start, steps):
       optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, step))
       out = task.train_step(next(data), model, optimizer, metrics={}, reducer=reducer,
-                            clip_norm=opt_cfg.gradient_clip_norm)
+                            clip_norm=opt_cfg.gradient_clip_norm, step=step + 1)
       if step % log_every == 0 or step == steps - 1:
         loss = float(out[task.loss])
         logs.append({'step': step, 'loss': loss, 'elapsed_s': time.perf_counter() - t0})

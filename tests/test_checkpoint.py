@@ -74,8 +74,10 @@ def test_resume_continues_bit_identically(tmp_path):
   import mmt_amd
   from mmt_amd import checkpoint, distribute, optimization
   exp = tiny_experiment(S=256, radius=32, n_global=8)
-  exp.task.model.encoder.mmt.hidden_dropout_prob = 0.0
-  exp.task.model.encoder.mmt.attention_probs_dropout_prob = 0.0
+  # dropout ON: the masks are a function of (train step, micro step, rank), so the resumed run draws the
+  # masks the uninterrupted run drew for steps 4 and 5
+  exp.task.model.encoder.mmt.hidden_dropout_prob = 0.1
+  exp.task.model.encoder.mmt.attention_probs_dropout_prob = 0.1
 
   def fresh():
     task = mmt_amd.tasks.get_task(exp.task, compute_dtype=torch.bfloat16)
@@ -88,16 +90,17 @@ def test_resume_continues_bit_identically(tmp_path):
     return task, model, reducer, opt, batch
 
   task, model, reducer, opt, batch = fresh()
-  for _ in range(3):
-    task.train_step(batch, model, opt, reducer=reducer, clip_norm=1.0)
+  for step in (1, 2, 3):
+    task.train_step(batch, model, opt, reducer=reducer, clip_norm=1.0, step=step)
   path = checkpoint.save(str(tmp_path), 3, model, opt)
-  for _ in range(2):
-    task.train_step(batch, model, opt, reducer=reducer, clip_norm=1.0)
+  for step in (4, 5):
+    task.train_step(batch, model, opt, reducer=reducer, clip_norm=1.0, step=step)
   want = [p.detach().clone() for p in model.parameters()]
 
   task2, model2, reducer2, opt2, batch2 = fresh()
-  assert checkpoint.restore(path, model2, opt2) == 3
-  for _ in range(2):
-    task2.train_step(batch2, model2, opt2, reducer=reducer2, clip_norm=1.0)
+  start = checkpoint.restore(path, model2, opt2)     # no refresh_shadow(): the shadows re-sync by themselves
+  assert start == 3
+  for step in (start + 1, start + 2):
+    task2.train_step(batch2, model2, opt2, reducer=reducer2, clip_norm=1.0, step=step)
   for (n, p), q in zip(model2.named_parameters(), want):
     assert torch.equal(p, q), n

@@ -97,3 +97,102 @@ def test_bucketed_allreduce_world2(reduce):
       assert torch.allclose(a, b, atol=1e-6), (a - b).abs().max()
   for a, b in zip(out[0], out[1]):
     assert torch.equal(a, b)
+
+
+# ---- scale_loss=True (pretraining.py:286-296): each replica differentiates loss / num_replicas and the
+# ---- optimizer SUMs the replicas -> same update as one process running both shards as micro-batches
+class _TinyTaskConfig:
+  def __init__(self, scale_loss):
+    self.scale_loss = scale_loss
+
+
+class _TinyModel(torch.nn.Module):
+  def __init__(self):
+    super().__init__()
+    self.net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
+
+  def forward(self, x, training=False):
+    return {'y': self.net(x)}
+
+
+def _tiny_task(scale_loss, num_replicas):
+  from mmt_amd import tasks
+
+  class T(tasks._TaskBase):
+    def build_losses(self, labels, outputs, metrics=None):
+      return (outputs['y'][:, 0] - labels['t']).pow(2).mean()
+  return T(_TinyTaskConfig(scale_loss), num_replicas=num_replicas)
+
+
+def _tiny_batch(rank):
+  g = torch.Generator().manual_seed(7 + rank)
+  return {'word_ids': torch.zeros(4, 1), 'x': torch.randn(4, 6, generator=g)}, {'t': torch.randn(4, generator=g)}
+
+
+class _DropWordIds(torch.nn.Module):     # train_step reads the batch size off inputs['word_ids']
+  def __init__(self, m):
+    super().__init__(); self.m = m
+
+  def forward(self, word_ids, x, training=False):
+    return self.m(x, training)
+
+
+def _scale_loss_worker(rank, world, port, out):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  from mmt_amd import distribute, tasks
+  strategy = distribute.get_distribution_strategy('mirrored', num_gpus=0)
+  task = _tiny_task(True, world)
+  assert tasks.gradient_reduce_mode(task.task_config) == 'sum'
+  torch.manual_seed(3)
+  model = _DropWordIds(_TinyModel())
+  reducer = strategy.make_reducer(list(model.parameters()), reduce=tasks.gradient_reduce_mode(task.task_config))
+  opt = torch.optim.SGD(model.parameters(), lr=0.5)
+  task.train_step(_tiny_batch(rank), model, opt, reducer=reducer, micro_batch_size=4, step=1)
+  out[rank] = [p.detach().clone() for p in model.parameters()]
+  dist.destroy_process_group()
+
+
+def test_scale_loss_world2_equals_micro_batched_single_process():
+  world = 2
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_scale_loss_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+  from mmt_amd import distribute, tasks
+  task = _tiny_task(False, 1)
+  torch.manual_seed(3)
+  model = _DropWordIds(_TinyModel())
+  init = [p.detach().clone() for p in model.parameters()]
+  reducer = distribute.DataParallelStrategy(None).make_reducer(list(model.parameters()))
+  opt = torch.optim.SGD(model.parameters(), lr=0.5)
+  (i0, l0), (i1, l1) = _tiny_batch(0), _tiny_batch(1)
+  both = ({k: torch.cat([i0[k], i1[k]]) for k in i0}, {k: torch.cat([l0[k], l1[k]]) for k in l0})
+  task.train_step(both, model, opt, reducer=reducer, micro_batch_size=4, step=1)
+  want = [p.detach() for p in model.parameters()]
+  assert max(float((a - b).abs().max()) for a, b in zip(want, init)) > 1e-3      # the step moved them
+  for rank in range(world):
+    for a, b in zip(out[rank], want):
+      assert torch.allclose(a, b, atol=1e-6), float((a - b).abs().max())
+
+
+def test_bench_launches_its_own_ranks():
+  """`python bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself (children; the parent never
+  touches a GPU), runs the gradient exchange over gloo here, and relays ONE JSON line."""
+  import json
+  import subprocess
+  import sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
+  env['MMT_DIST_BACKEND'] = 'gloo'
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--mode', 'allreduce',
+                      '--allreduce-mb', '4', '--steps', '3', '--warmup', '1'],
+                     env=env, capture_output=True, text=True, timeout=240)
+  assert r.returncode == 0, r.stderr[-2000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, r.stdout
+  d = json.loads(lines[0])
+  assert d['n_gpus'] == 2 and d['config']['ranks_seen'] == 2 and d['config']['backend'] == 'gloo'
+  assert d['config']['parallelism'] == 'dp2' and d['steps'] == 3 and d['value'] > 0
+  # asking for more ranks than were launched is an error, not a silent 1-rank run
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--mode', 'allreduce'],
+                     env=dict(env, WORLD_SIZE='1', RANK='0'), capture_output=True, text=True, timeout=120)
+  assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)

@@ -71,7 +71,7 @@ def test_two_ranks_on_one_gpu_average_their_bucket_gradients():
   assert torch.allclose(r0.double(), (l0.double() + l1.double()) / 2, atol=1e-6, rtol=1e-5)
 
 
-def _step_worker(rank, world, port, out):
+def _step_worker(rank, world, port, out, scale_loss=False):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                     HSA_ENABLE_IPC_MODE_LEGACY='0')
   import torch.distributed as dist
@@ -84,10 +84,15 @@ def _step_worker(rank, world, port, out):
   exp.task.model.encoder.mmt.attention_probs_dropout_prob = 0.0
 
   def make(num_replicas, strategy):
+    # scale_loss=True (pretraining.py:286-296) on the data-parallel side only: gradient of loss / replicas,
+    # SUM over replicas -- the single-process reference below keeps the plain micro-batch mean
+    exp.task.scale_loss = bool(scale_loss and num_replicas > 1)
     task = mmt_amd.tasks.get_task(exp.task, compute_dtype=torch.bfloat16, num_replicas=num_replicas)
     torch.manual_seed(6)
     model = task.build_model().cuda()
-    reducer = strategy.make_reducer(list(model.parameters()), reduce='mean')
+    reduce = mmt_amd.tasks.gradient_reduce_mode(exp.task)
+    assert reduce == ('sum' if exp.task.scale_loss else 'mean')
+    reducer = strategy.make_reducer(list(model.parameters()), reduce=reduce)
     opt = optimization.create_optimizer(model, exp.trainer.optimizer_config, reducer=reducer)
     optimization.set_learning_rate(opt, 1e-3)
     return task, model, reducer, opt
@@ -108,13 +113,52 @@ def _step_worker(rank, world, port, out):
   dist.destroy_process_group()
 
 
-def test_data_parallel_train_step_equals_micro_batched_single_process():
-  """Two ranks x 2 samples with the deferred 1/world mean == one process x 2 micro-batches of 2."""
+@pytest.mark.parametrize('scale_loss', [False, True], ids=['mean', 'scale_loss-sum'])
+def test_data_parallel_train_step_equals_micro_batched_single_process(scale_loss):
+  """Two ranks x 2 samples with the deferred 1/world mean (or scale_loss + SUM) == one process x 2
+  micro-batches of 2."""
   world = 2
   mgr = mp.Manager()
   out = mgr.dict()
-  mp.spawn(_step_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+  mp.spawn(_step_worker, args=(world, _free_port(), out, scale_loss), nprocs=world, join=True)
   (w0, m0, p0), (w1, m1, p1) = out[0], out[1]
   assert torch.equal(p0, p1)                      # replicas stay in sync
   assert m0 > 1e-4                                 # the step moved the parameters ...
   assert max(w0, w1) < 1e-6 + 1e-3 * m0            # ... to the same place as the single-process reference
+
+
+def _dropout_worker(rank, world, port, out):
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                    HSA_ENABLE_IPC_MODE_LEGACY='0')
+  import torch.distributed as dist
+  import mmt_amd
+  dist.init_process_group('gloo')
+  torch.cuda.set_device(0)
+  exp = tiny_experiment(S=256, radius=32, n_global=8)
+  exp.task.model.encoder.mmt.hidden_dropout_prob = 0.5
+  exp.task.model.encoder.mmt.attention_probs_dropout_prob = 0.5
+  task = mmt_amd.tasks.get_task(exp.task, compute_dtype=torch.bfloat16, num_replicas=world)
+  torch.manual_seed(5)
+  model = task.build_model().cuda()
+  inputs, _ = next(task.build_inputs(exp.task.train_data, device='cuda', rank=0, batch_size=2))   # SAME data on both ranks
+  enc = {k: v for k, v in inputs.items() if k not in ('mlm_positions', 'mpp_positions')}
+  seqs = []
+  for step in (1, 1, 2):
+    mmt_amd.fused.set_seed_stream(step, 0, rank)
+    with torch.no_grad():
+      seqs.append(model.encoder(**enc, training=True)['sequence_output'].float().cpu())
+  out[rank] = seqs
+  dist.destroy_process_group()
+
+
+def test_replicas_draw_different_dropout_masks():
+  """Same weights, same inputs, same step: the ranks' dropout masks differ (seeded by rank), a rank
+  repeats its own masks for the same step and changes them with the step."""
+  world = 2
+  mgr = mp.Manager()
+  out = mgr.dict()
+  mp.spawn(_dropout_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+  a, b = out[0], out[1]
+  assert torch.equal(a[0], a[1]) and torch.equal(b[0], b[1])
+  assert not torch.equal(a[0], a[2])
+  assert not torch.equal(a[0], b[0])

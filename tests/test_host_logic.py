@@ -149,3 +149,47 @@ def test_losses_divide_no_nan():
   w = torch.tensor([[1., 0., 1.], [0., 0., 1.]])
   ref = (torch.nn.functional.cross_entropy(logits.view(-1, 5), labels.view(-1), reduction='none') * w.view(-1)).sum() / 3
   assert abs(float(wsce(logits, labels, w)) - float(ref)) < 1e-6
+
+
+def test_stale_bf16_shadow_is_resynchronised_after_a_master_write():
+  """`layers._param_weight` hands the forward the optimizer's bf16 shadow of an fp32 master; a torch-side
+  write to the master (load_state_dict, checkpoint restore) must not leave the forward on old weights."""
+  import torch
+  from mmt_amd import layers
+  p = torch.nn.Parameter(torch.arange(8, dtype=torch.float32))
+  p._mmt_shadow = p.detach().to(torch.bfloat16)
+  p._mmt_shadow_version = p._version
+  assert layers._param_weight(p, torch.bfloat16) is p._mmt_shadow
+  with torch.no_grad():
+    p.copy_(torch.full((8,), 3.0))
+  w = layers._param_weight(p, torch.bfloat16)
+  assert w is p._mmt_shadow and torch.equal(w.float(), torch.full((8,), 3.0))
+  m = torch.nn.Linear(4, 2, bias=False)
+  m.weight._mmt_shadow = m.weight.detach().to(torch.bfloat16)
+  m.weight._mmt_shadow_version = m.weight._version
+  m.load_state_dict({'weight': torch.ones(2, 4)})
+  assert torch.equal(layers._param_weight(m.weight, torch.bfloat16).float(), torch.ones(2, 4))
+
+
+def test_dropout_seed_stream_depends_on_step_micro_step_and_rank():
+  from mmt_amd import fused
+  def draw(step, micro, rank, n=3):
+    fused.set_seed_stream(step, micro, rank)
+    return [fused.next_seed(0) for _ in range(n)]
+  a = draw(5, 0, 0)
+  assert a == draw(5, 0, 0)                          # resumable: a pure function of its arguments
+  assert len(set(a)) == 3
+  for other in (draw(6, 0, 0), draw(5, 1, 0), draw(5, 0, 1)):
+    assert not set(a) & set(other)
+
+
+def test_gradient_reduce_mode_follows_scale_loss(monkeypatch):
+  from mmt_amd import tasks
+  class C:
+    scale_loss = True
+  assert tasks.gradient_reduce_mode(C()) == 'sum'       # pretraining.py:286-296 + SUM in apply_gradients
+  C.scale_loss = False
+  monkeypatch.delenv('MMT_REFERENCE_SUM', raising=False)
+  assert tasks.gradient_reduce_mode(C()) == 'mean'
+  monkeypatch.setenv('MMT_REFERENCE_SUM', '1')
+  assert tasks.gradient_reduce_mode(C()) == 'sum'

@@ -1,6 +1,7 @@
 """Dev tool: times the attention forward/backward entry points at BASELINE config 3 (not part of the product)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'multimodal-long-transformer-2021_amd'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multimodal-long-transformer-2021_amd'))
 import torch, mmt_amd
 torch.manual_seed(0)
 B, S, N = 4, 4096, 12

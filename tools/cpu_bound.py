@@ -1,6 +1,7 @@
 """Dev tool: is the train step host-bound?  Host enqueue time vs GPU completion time per step."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'multimodal-long-transformer-2021_amd'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multimodal-long-transformer-2021_amd'))
 import torch
 from mmt_amd import benchmarks
 import bench

@@ -1,7 +1,8 @@
 """Dev tool: replay one train step as a hipGraph to see the GPU-bound step time (not the product path:
 the capture bakes lr / seeds of one step)."""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'multimodal-long-transformer-2021_amd'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multimodal-long-transformer-2021_amd'))
 import torch
 from mmt_amd import benchmarks
 import bench

@@ -1,6 +1,7 @@
 """Dev tool: torch.profiler view of one train step at BASELINE config 3 (op -> kernels), not part of the product."""
 import os, sys, json
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'multimodal-long-transformer-2021_amd'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multimodal-long-transformer-2021_amd'))
 import torch
 from torch.profiler import profile, ProfilerActivity
 import mmt_amd

@@ -1,10 +1,11 @@
 """Dev tool: (re)measure the library-GEMM selections shipped in mmt_amd/tuned/ on an MI355X.
   PYTORCH_TUNABLEOP_ENABLED=1 PYTORCH_TUNABLEOP_TUNING=1 PYTORCH_TUNABLEOP_FILENAME=gpurun_out/tuned_.csv \\
-  PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=30 python tools_tune_gemms.py
+  PYTORCH_TUNABLEOP_MAX_TUNING_DURATION_MS=30 python tools/tune_gemms.py
 runs a few train steps of BASELINE configs 3, 5 (g = 8, 32, 128) and 2 (fp32) so that TunableOp sees every GEMM
 shape of those configurations; copy gpurun_out/tuned_0.csv over the shipped file afterwards."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'multimodal-long-transformer-2021_amd'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multimodal-long-transformer-2021_amd'))
 import torch
 from mmt_amd import benchmarks
 import bench

@@ -1,6 +1,7 @@
 """Dev tool: correctness + speed of mmt_wgrad_accumulate vs torch.mm (not part of the product)."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'multimodal-long-transformer-2021_amd'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multimodal-long-transformer-2021_amd'))
 import torch
 from mmt_amd import fused
 torch.manual_seed(0)
