@@ -87,6 +87,8 @@ def test_dense_operator_backward(cfg, dtype):
     dict(B=1, S=200, N=2, R=49, radius=20, g0=150, ng=5, id_mode=2, m=12, P=10, r=2),
     dict(B=1, S=96, N=1, R=0, radius=8, g0=0, ng=1),
     dict(B=1, S=512, N=2, R=32, radius=64, g0=400, ng=8, m=12),
+    # BASELINE config 2 shape: S=1024 = 2 + 28^2 + 238 text, radius 64, 8 globals [786,794) (fp32 there)
+    dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'id_mode')))
 def test_structured_pattern_backward(cfg, dtype):
   run_bwd(dtype=dtype, dense=False, **cfg)

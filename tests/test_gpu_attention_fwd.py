@@ -152,7 +152,7 @@ def test_config3_shape_against_oracle_sample():
   assert float((out1.float() - 1).abs().max()) < 1e-2     # rows of P sum to 1
 
 
-@pytest.mark.parametrize('ng', [8, 128])
+@pytest.mark.parametrize('ng', [8, 32, 128])
 def test_config5_shape_forward_backward(ng):
   """BASELINE config 5 shape (S=8192 = 2+88^2+446, radius 64, g globals, bf16): one head against the
   dense oracle (forward), all heads finite + normalised; backward finite and dV rows sum to dO."""

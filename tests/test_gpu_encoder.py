@@ -147,3 +147,32 @@ def test_bucketed_direct_gradients_equal_plain_autograd():
       continue
     err = float((g0 - g1).abs().max()) / max(1e-3, float(g0.abs().max()))
     assert err < 2e-2, (name, err)        # bf16 rounding of the plain path's accumulated grads
+
+
+def _full_config(cfg_over, dtype):
+  import bench
+  import mmt_amd
+  cfg = dict(bench.config3(), **cfg_over)
+  step, info = mmt_amd.make_train_step_bench(cfg, torch.device('cuda', 0), 0, 1, dtype=dtype)
+  losses = [float(step()['loss']) for _ in range(6)]
+  torch.cuda.synchronize()
+  assert all(np.isfinite(losses)), losses
+  assert losses[-1] < losses[0], losses          # same batch every step: the loss must fall
+  return losses
+
+
+def test_config2_full_size_train_step_fp32():
+  """BASELINE config 2 at full size (BERT-base dims, S=1024 = 2+28^2+238, radius 64, 8 globals [786,794),
+  fp32 compute, B=8): the train step runs, stays finite and reduces the loss."""
+  _full_config(dict(S=1024, P=28, B=8, g0=2 + 28 * 28, ng=8), torch.float32)
+
+
+@pytest.mark.parametrize('ng', [8, 32, 128])
+def test_config5_full_size_train_step_bf16(ng):
+  """BASELINE config 5 at full size (S=8192 = 2+88^2+446, radius 64, g global tokens, bf16, B=2 per GPU)."""
+  _full_config(dict(S=8192, P=88, B=2, g0=2 + 88 * 88, ng=ng), torch.bfloat16)
+
+
+def test_config3_full_size_train_step_bf16():
+  """BASELINE config 3 (the bench workload) through the same closure bench.py times."""
+  _full_config(dict(), torch.bfloat16)
