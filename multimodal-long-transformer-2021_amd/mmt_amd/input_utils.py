@@ -11,6 +11,7 @@ from . import _lib
 from .ops import AttentionPattern, side_inputs
 
 CLS_ID, PATCH_ID, SEP_ID, ATT_ID = 101, 1, 102, 2   # [CLS], [PATCH]=[unused0], [SEP], [ATT]=[unused1]
+MASK_ID = 103                                         # [MASK] of the BERT vocabulary
 PATCH_START_UNUSED_INDEX = 104                        # src/data/data_utils.py:31
 
 
@@ -97,21 +98,27 @@ def synthetic_batch(data_cfg, batch_size: int, device, generator: Optional[torch
     inputs['valid_len'] = valid_len
   labels = {}
   if task == 'pretrain':
-    a, b = data_cfg.mlm_max_selections_per_seq, data_cfg.mpp_max_selections_per_seq
-    n_mlm = max(1, min(a, int(data_cfg.mlm_fraction_to_mask * max_text)))
-    n_mpp = min(b, int(data_cfg.mpp_fraction_to_mask * n_patch))
-    mlm_pos = torch.zeros(B, a, device=device, dtype=torch.int32)
-    mlm_pos[:, :n_mlm] = n_img + 1 + ri(0, max(1, max_text - 1), (B, n_mlm)) % (n_text[:, None] - 1).clamp(min=1)
-    mlm_w = torch.zeros(B, a, device=device, dtype=torch.int32); mlm_w[:, :n_mlm] = 1
-    mpp_pos = torch.zeros(B, b, device=device, dtype=torch.int32)
-    mpp_w = torch.zeros(B, b, device=device, dtype=torch.int32)
-    if n_mpp:
-      mpp_pos[:, :n_mpp] = 2 + ri(0, n_patch, (B, n_mpp))
-      mpp_w[:, :n_mpp] = 1
-    inputs.update(mlm_positions=mlm_pos, mpp_positions=mpp_pos)
-    labels.update(
-        mlm_label_ids=ri(1000, vocab_size, (B, a)), mlm_label_weights=mlm_w,
-        mpp_label_ids=ri(0, (2 ** data_cfg.output_channel_bits) ** 3, (B, b)), mpp_label_weights=mpp_w)
+    # MLM / MPP masking exactly as the reference's data pipeline applies it (`get_masking_fn`,
+    # data_utils.py:383-639), on the device: feature_pipeline.make_mlm_and_mpp_features
+    from . import feature_pipeline as fp
+    rf = lambda *shape: torch.rand(*shape, device=device, generator=g)
+    word_ids[torch.arange(B, device=device), (valid_len - 1).long()] = SEP_ID
+    feats = {'patch_token_ids': word_ids[:, :n_img].contiguous(), 'text_token_ids': word_ids[:, n_img:].contiguous(),
+             'num_text_wordpieces': n_text, 'patch_embeddings': inputs['patch_embeddings'],
+             'unnormalized_patch_embeddings': rf(B, n_patch, data_cfg.patch_size ** 2 * 3)}
+    randoms = {'mlm_item_keys': rf(B, max_text), 'mlm_value_u': rf(B, max_text), 'mlm_random_ids': ri(0, vocab_size, (B, max_text)),
+               'mpp_item_keys': rf(B, n_img), 'mpp_value_u': rf(B, n_img), 'mpp_random_ids': ri(0, vocab_size, (B, n_img))}
+    m = fp.make_mlm_and_mpp_features(
+        feats, randoms, max_seq_len=S, num_patches=n_patch, patch_size=data_cfg.patch_size, vocab_size=vocab_size,
+        mask_token_id=MASK_ID, unselectable_ids=(CLS_ID, SEP_ID, PATCH_ID, ATT_ID),
+        mlm_fraction_to_mask=data_cfg.mlm_fraction_to_mask, mpp_fraction_to_mask=data_cfg.mpp_fraction_to_mask,
+        mlm_max_selections_per_seq=data_cfg.mlm_max_selections_per_seq,
+        mpp_max_selections_per_seq=data_cfg.mpp_max_selections_per_seq,
+        output_channel_bits=data_cfg.output_channel_bits)
+    inputs.update(word_ids=m['word_ids'], patch_embeddings=m['patch_embeddings'],
+                  mlm_positions=m['mlm_positions'], mpp_positions=m['mpp_positions'])
+    labels.update(mlm_label_ids=m['mlm_label_ids'], mlm_label_weights=m['mlm_label_weights'],
+                  mpp_label_ids=m['mpp_label_ids'], mpp_label_weights=m['mpp_label_weights'])
     if 'itm' in (data_cfg.tasks or 'mlm,itm'):
       labels.update(itm_label_ids=ri(0, 2, (B,)),
                     itm_label_weights=torch.ones(B, device=device, dtype=torch.float32))
