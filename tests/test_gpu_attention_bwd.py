@@ -185,3 +185,32 @@ def test_dropout_mask_matches_oracle_forward_and_backward(path):
     got, want = t.grad.float().cpu().numpy(), ref[name]
     err = np.abs(got - want).max() / (max(1.0, np.abs(want).max()) if dtype == torch.bfloat16 else 1.0)
     assert err < tol, f'{name}: {err}'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_2d_ids_long_sequence_forward_backward_against_oracle(dtype):
+  """The `*_2d*.yaml` experiments at the long-sequence shape: S=4096 = 2 + 63^2 + 125, 2-D relative ids
+  (MmtRelativePositionGenerator, feature_utils.py:114-184: P=63, 2 core layers, R=49, m=12), radius 64 + 8 global
+  tokens, one head: output, LSE and every gradient against the dense oracle (ids >= R contribute 0, q1)."""
+  import mmt_amd
+  B, S, N, R, P, r, m = 1, 4096, 1, 49, 63, 2, 12
+  q, k, v, emb, bias = attention_inputs(B, S, N, R, seed=21)
+  dout = np.random.default_rng(22).standard_normal(q.shape).astype(np.float32)
+  if dtype == torch.bfloat16:
+    q, k, v, emb, bias, dout = (bf16_round(x) for x in (q, k, v, emb, bias, dout))
+  mask, ids = dense_side_inputs(B, S, None, 64, 3971, 8, 2, m, P, r)
+  assert ids.max() > R                                     # the cross-modal part ids lie outside the vocabulary
+  ref_o, ref_lse = oa.relative_attention_fwd(q, k, v, emb, bias, mask, ids)
+  ref = oa.relative_attention_bwd(dout, q, k, v, emb, bias, mask, ids)
+  dev = lambda x: torch.from_numpy(x).cuda().to(dtype).contiguous()
+  tq, tk, tv, te, tb = (dev(x).requires_grad_(True) for x in (q, k, v, emb, bias))
+  pat = mmt_amd.AttentionPattern(local_radius=64, global_start=3971, n_global=8, id_mode=2, max_dist=m,
+                                 patches_per_row=P, core_layers=r)
+  out = mmt_amd.relative_attention(tq, tk, tv, te, tb, pattern=pat)
+  out.backward(dev(dout))
+  tol_o, tol_g = (2e-2, 3e-2) if dtype == torch.bfloat16 else (1e-3, 2e-3)
+  assert np.abs(out.detach().float().cpu().numpy() - ref_o).max() < tol_o
+  for name, t in (('dq', tq), ('dk', tk), ('dv', tv), ('drel_emb', te), ('drel_bias', tb)):
+    got, want = t.grad.float().cpu().numpy(), ref[name]
+    err = np.abs(got - want).max() / (max(1.0, np.abs(want).max()) if dtype == torch.bfloat16 else 1.0)
+    assert err < tol_g, f'{name}: {err}'
