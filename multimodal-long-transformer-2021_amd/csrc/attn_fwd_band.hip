@@ -187,25 +187,61 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
 #pragma unroll
       for (int i = 0; i < 16; ++i) s2[i] = fmaf(c[i], p.sscale, relc);
     } else if (plain) {                                        // ---- class B (HAS_REL, mixed ids)
+      // Register i holds key offset ci = (i & 3) + 8 (i >> 2) (+ 4 in the upper half-wave) of the tile:
+      // d = o + ci (+4) - r with o = k0 - q0 and r = 0..31.  In the two tiles next to the diagonal one, half of the
+      // registers are beyond the clip distance for EVERY lane and take the clipped constant without a gather:
+      // o >= m + 15 -> registers 8..15 (ci >= 16) have d >= m;  o <= -(m + 15) -> registers 0..7 (ci <= 11) have d <= -m.
       const int abase = trow_addr + 4 * (m + dbase), alo = trow_addr, ahi = trow_addr + 8 * m;
+      const int o = k0 - q0;
+      if (o >= m + 15) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int a = med3i(abase + 4 * ((i & 3) + 8 * (i >> 2)), alo, ahi);
-        s2[i] = fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)a);
+        for (int i = 0; i < 8; ++i) {
+          const int a = med3i(abase + 4 * ((i & 3) + 8 * (i >> 2)), alo, ahi);
+          s2[i] = fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)a);
+        }
+#pragma unroll
+        for (int i = 8; i < 16; ++i) s2[i] = fmaf(c[i], p.sscale, relfp);
+      } else if (o <= -(m + 15)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s2[i] = fmaf(c[i], p.sscale, relfn);
+#pragma unroll
+        for (int i = 8; i < 16; ++i) {
+          const int a = med3i(abase + 4 * ((i & 3) + 8 * (i >> 2)), alo, ahi);
+          s2[i] = fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)a);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int a = med3i(abase + 4 * ((i & 3) + 8 * (i >> 2)), alo, ahi);
+          s2[i] = fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)a);
+        }
       }
     } else if (in_range && seg_all && no_gkey && one_id) {     // ---- class D (band edge)
-      const unsigned W2 = 2u * (unsigned)W;
+      // masked <=> d = dbase + ci outside [-W, W]; when only one side can fail in this tile: one compare of the
+      // literal ci against a per-lane bound, one select between the row constant with and without the additive
+      // mask, one fma
+      const float relm = relc + p.mask_add;
+      if (dmin >= -W) {                    // only d > W can fail: masked iff ci > W - dbase
+        const int bound = W - dbase;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const unsigned dd = (unsigned)(dbase + (i & 3) + 8 * (i >> 2) + W);
-        s2[i] = fmaf(c[i], p.sscale, relc) + (dd <= W2 ? 0.f : p.mask_add);
+        for (int i = 0; i < 16; ++i) s2[i] = fmaf(c[i], p.sscale, ((i & 3) + 8 * (i >> 2)) > bound ? relm : relc);
+      } else if (dmax <= W) {              // only d < -W can fail: masked iff ci < -W - dbase
+        const int bound = -W - dbase;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s2[i] = fmaf(c[i], p.sscale, ((i & 3) + 8 * (i >> 2)) < bound ? relm : relc);
+      } else {                             // a radius below the tile size: both sides
+        const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          s2[i] = fmaf(c[i], p.sscale, (unsigned)(dbase + (i & 3) + 8 * (i >> 2) + W) <= W2 ? relc : relm);
       }
     } else if (in_range && seg_all && one_id && !ignore_band && (dmin > W || dmax < -W)) {   // ---- class G
       // a tile that lies wholly outside the band: only its global keys are visible (every band wave meets one)
       const unsigned gb = (unsigned)(k0 + 4 * h - p.pat.g0), ng = (unsigned)p.pat.ng;
+      const float relm = relc + p.mask_add;
 #pragma unroll
       for (int i = 0; i < 16; ++i)
-        s2[i] = fmaf(c[i], p.sscale, relc) + (gb + (unsigned)((i & 3) + 8 * (i >> 2)) < ng ? 0.f : p.mask_add);
+        s2[i] = fmaf(c[i], p.sscale, gb + (unsigned)((i & 3) + 8 * (i >> 2)) < ng ? relc : relm);
     } else {                                                   // ---- class C (general)
       const int kb = k0 + 4 * h;
       const bool qv = q < valid_len;
