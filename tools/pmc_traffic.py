@@ -1,9 +1,9 @@
-"""Dev tool: per-kernel means of FETCH_SIZE / WRITE_SIZE from two rocprofv3 --pmc passes -> profiles/attn_fwd_traffic.json.
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_f -o f -- python3 tools/bwd_timing.py
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_w -o w -- python3 tools/bwd_timing.py
-  python tools/pmc_traffic.py
-gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE x2 for wide streaming reads, WRITE_SIZE as is; unit KB."""
-import csv, json, collections
+"""Dev tool: per-kernel means of FETCH_SIZE / WRITE_SIZE from two rocprofv3 --pmc passes over tools/attn_pmc_workload.py
+-> profiles/attn_traffic.json (read by bench.py for roofline.traffic / roofline_bwd.traffic), stamped with the commit.
+gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE x2 for wide (16 B/lane) streaming reads, WRITE_SIZE as is; unit KB."""
+import csv, json, collections, subprocess, sys
+sys.path.insert(0, '.')
+import bench
 def means(path, counter):
   acc = collections.defaultdict(list)
   for r in csv.DictReader(open(path)):
@@ -12,19 +12,22 @@ def means(path, counter):
   return {k: sum(v[len(v) // 4:]) / len(v[len(v) // 4:]) for k, v in acc.items()}     # skip the first (cold) quarter
 f = means('gpurun_out/pmc_f/f_counter_collection.csv', 'FETCH_SIZE')
 w = means('gpurun_out/pmc_w/w_counter_collection.csv', 'WRITE_SIZE')
-fwd = [k for k in f if 'attn_fwd_band' in k][0]
-comb = [k for k in f if 'rows_combine' in k][0]
-fetch, write = f[fwd] + f[comb], w[fwd] + w[comb]
+is_fwd = lambda k: 'attn_fwd' in k or 'rows_combine' in k
+hbm = lambda ks: int(sum((2 * f[k] + w.get(k, 0.0)) * 1024 for k in ks))
+fwd_k, bwd_k = [k for k in f if is_fwd(k)], [k for k in f if not is_fwd(k)]
+cfg = bench.config3()
+_, fb, bb = bench.attn_algorithmic(cfg, 2)
+commit = subprocess.check_output(['git', 'rev-parse', '--short=12', 'HEAD']).decode().strip()
+dirty = bool(subprocess.check_output(['git', 'status', '--porcelain', '--', 'multimodal-long-transformer-2021_amd/csrc']).decode().strip())
 out = {
-  'kernel': 'one attention-forward call (config 3, B=4): attn_fwd_band_bf16_kernel<32,true> + attn_rows_combine_kernel',
-  'FETCH_SIZE_KB': round(fetch, 1), 'WRITE_SIZE_KB': round(write, 1),
-  'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE (tools/bwd_timing.py, '
-            'tools/pmc_traffic.py); gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE x2 for wide (16 B/lane) '
-            'streaming reads, WRITE_SIZE as is; unit KB',
-  'hbm_bytes_per_launch': int((2 * fetch + write) * 1024),
-  'algorithmic_bytes_per_launch': 101649408,
-  'note': 're-measured at round-1 v15; all_kernels_raw_KB = per-launch means of every attention kernel of one forward+backward call',
-  'all_kernels_raw_KB': {k: {'FETCH_SIZE': round(f[k], 1), 'WRITE_SIZE': round(w.get(k, 0.0), 1)} for k in f},
+  'commit': commit + ('+uncommitted csrc changes' if dirty else ''),
+  'workload': 'tools/attn_pmc_workload.py: the attention forward and backward calls bench.py times (config 3, B=4, dropout 0.1)',
+  'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; per-kernel means over the last 3/4 '
+            'of the launches; gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE x2 for wide (16 B/lane) streaming reads, '
+            'WRITE_SIZE as is; unit KB',
+  'fwd_hbm_bytes_per_launch': hbm(fwd_k), 'fwd_algorithmic_bytes_per_launch': fb * cfg['B'],
+  'bwd_hbm_bytes_per_launch': hbm(bwd_k), 'bwd_algorithmic_bytes_per_launch': bb * cfg['B'],
+  'per_kernel_raw_KB': {k: {'FETCH_SIZE': round(f[k], 1), 'WRITE_SIZE': round(w.get(k, 0.0), 1)} for k in f},
 }
-json.dump(out, open('profiles/attn_fwd_traffic.json', 'w'), indent=1)
+json.dump(out, open('profiles/attn_traffic.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
