@@ -26,6 +26,24 @@ __device__ __forceinline__ void tile_to_lds(unsigned char* lds, const bf16x8 (&v
     *reinterpret_cast<bf16x8*>(lds + row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16) = v[u];
   }
 }
+// E rows in table-column order (row c <- relative id icol(m, c); ids >= R read as zeros through the buffer
+// range check), staged ONCE per workgroup as Rp/32 swizzled 32 x 128-byte tile images at the start of LDS.  The
+// table products (E . Q^T), the dQ += E^T . dRel^T product and the mixed-id table rebuilds of the dK/dV pass
+// read their fragments from it instead of waiting for L2 once per item / per mixed-id tile.
+template <int Rp>
+__device__ __forceinline__ void stage_e_image(unsigned char* elds, const void* emb, int n, int N, int R, int m, int tid) {
+  using T = __bf16;
+  const T* Eb = reinterpret_cast<const T*>(emb) + (long)n * 64;
+  const unsigned es1b = (unsigned)N * 128;
+  const auto re = make_rsrc(Eb, (unsigned)(R - 1) * es1b + 128);
+#pragma unroll
+  for (int c0 = 0; c0 < Rp * 8; c0 += 256) {
+    const int ci = c0 + tid, row = ci >> 3, ch = ci & 7, rt = row & 31;
+    const bf16x8 e = buf16(re, (unsigned)icol(m, row) * es1b + ch * 16, 0u);
+    *reinterpret_cast<bf16x8*>(elds + (row >> 5) * 4096 + rt * 128 + ((((ch >> 2) ^ ((rt >> 1) & 1))) << 6) + (ch & 3) * 16) = e;
+  }
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -42,7 +60,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
-  unsigned char* wl = smem + wave * L::kDq;
+  constexpr int kEImg = HAS_REL ? Rp * 128 : 0;
+  unsigned char* elds = smem;
+  unsigned char* wl = smem + kEImg + wave * L::kDq;
   float* tab = reinterpret_cast<float*>(wl);
   float* dtab = reinterpret_cast<float*>(wl + L::kTab);
   unsigned char* xlds = wl + 2 * L::kTab;
@@ -54,20 +74,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   const int n_split_blocks = per_bn * p.B * p.N;
   const bool split_item = (int)blockIdx.x < n_split_blocks;
   int bn, q0, chunk = 0, gblk = 0, band_wg = 0;
+  bool live = true;
   if (split_item) {
     bn = blockIdx.x / per_bn;
     const int item = (blockIdx.x - bn * per_bn) * 4 + wave;
-    if (item >= p.n_chunks * p.n_gblk) return;
-    gblk = item / p.n_chunks;
+    live = item < p.n_chunks * p.n_gblk;
+    gblk = live ? item / p.n_chunks : 0;
     chunk = item - gblk * p.n_chunks;
     q0 = p.pat.g0 + gblk * 32;
   } else {
     band_wg = xcd_remap(blockIdx.x - n_split_blocks, p.n_band_blocks);
     bn = band_wg / nqb;
     q0 = (band_wg - bn * nqb) * 128 + wave * 32;
-    if (q0 >= p.S) return;
+    live = q0 < p.S;
   }
   const int b = bn / p.N, n = bn - b * p.N;
+  if (HAS_REL) {           // every wave of the workgroup takes part (the plane, hence E, is the same for all four)
+    stage_e_image<Rp>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
+    __syncthreads();
+  }
+  if (!live) return;
   const int q = q0 + r;
   const bool q_ok = q < p.S;
   const int valid_len = p.valid_len ? p.valid_len[b] : p.S;
@@ -126,15 +152,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     float* bias_ts = reinterpret_cast<float*>(xlds);
     if (lane < Rp)
       bias_ts[lane] = (p.bias && icol(m, lane) < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)icol(m, lane) * p.N + n] * p.tscale : 0.f;   // by column
-    const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
-    const unsigned es1b = (unsigned)p.N * 128;
-    const auto re = make_rsrc(Eb, (unsigned)(p.R - 1) * es1b + 128);
     wave_lds_sync();
 #pragma unroll
     for (int rb = 0; rb < Rp / 32; ++rb) {
       Frag<T> ef;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) ef.v[s] = buf16(re, (unsigned)icol(m, rb * 32 + r) * es1b + 64 * h + 16 * s, 0u);   // row r <- id of column rb*32 + r
+      frag_from_tile(ef, elds + rb * 4096, lane);   // row r <- E row of table column rb*32 + r
       f32x16 c = {0};
       c = mma_rows(ef, qf, c);
 #pragma unroll
@@ -293,25 +315,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   }
 
   if (HAS_REL) {
-    // (1) dQ^T += E^T[d x id] . dRel^T[id x q]
-    const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
-    const unsigned es1b = (unsigned)p.N * 128;
-    const auto re = make_rsrc(Eb, (unsigned)(p.R - 1) * es1b + 128);
+    // (1) dQ^T += E^T[d x column] . dRel^T[column x q], both in table-column order: the E image of the workgroup
+    //     serves the transposed reads as it stands (columns that carry no relative id hold zero rows of E and
+    //     zero dRel)
 #pragma unroll
     for (int rb = 0; rb < Rp / 32; ++rb) {
       float vals[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int id = rb * 32 + kap(i, h);
-        vals[i] = id < p.R ? dtrow[tcol(1, m, id)] : 0.f;
-      }
-      bf16x8 et[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) et[u] = buf16(re, (unsigned)(lane >> 3) * es1b + (lane & 7) * 16, (unsigned)(rb * 32 + 8 * u) * es1b);
-      tile_to_lds(xlds, et, lane);
-      wave_lds_sync();
-      mma_xt_hilo(a0, a1, VTile<T>{}, xlds, vals, lane);
-      wave_lds_sync();
+      for (int i = 0; i < 16; ++i) vals[i] = dtrow[rb * 32 + kap(i, h)];
+      mma_xt_hilo(a0, a1, VTile<T>{}, elds + rb * 4096, vals, lane);
     }
   }
   if (q_ok && !(p.skip_global && is_global(p.pat, q))) {
@@ -349,8 +361,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     for (int w2 = 0; w2 < 4; ++w2) {
       const int q0w = q0 + 32 * w2;
       if (q0w >= p.S) break;
-      const float* dtab_w = reinterpret_cast<const float*>(smem + w2 * L::kDq + L::kTab);
-      const unsigned char* xlds_w = smem + w2 * L::kDq + 2 * L::kTab;
+      const float* dtab_w = reinterpret_cast<const float*>(smem + kEImg + w2 * L::kDq + L::kTab);
+      const unsigned char* xlds_w = smem + kEImg + w2 * L::kDq + 2 * L::kTab;
       float vals[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -383,7 +395,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
-  unsigned char* wl = smem + wave * L::kDkv;
+  constexpr int kEImg = HAS_REL ? Rp * 128 : 0;
+  unsigned char* elds = smem;
+  unsigned char* wl = smem + kEImg + wave * L::kDkv;
   float* tab = reinterpret_cast<float*>(wl);
   unsigned char* qlds = wl + L::kTab;
   unsigned char* dolds = qlds + L::kTile;
@@ -407,17 +421,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   int bn, k0, chunk = 0, gblk = 0, blk;
   plane_major_map(blockIdx.x, p.B * p.N, per_bn, nkb, bn, blk);
   const bool split_item = blk < per_bn;
+  bool live = true;
   if (split_item) {
     const int item = blk * 4 + wave;
-    if (item >= p.n_chunks * p.n_gblk) return;
-    gblk = item / p.n_chunks;
+    live = item < p.n_chunks * p.n_gblk;
+    gblk = live ? item / p.n_chunks : 0;
     chunk = item - gblk * p.n_chunks;
     k0 = p.pat.g0 + gblk * 32;
   } else {
     k0 = (blk - per_bn) * 128 + wave * 32;
-    if (k0 >= p.S) return;
+    live = k0 < p.S;
   }
   const int b = bn / p.N, n = bn - b * p.N;
+  if (HAS_REL) {
+    stage_e_image<Rp>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
+    __syncthreads();
+  }
+  if (!live) return;
   const int k = k0 + r;
   const bool k_ok = k < p.S;
   const int valid_len = p.valid_len ? p.valid_len[b] : p.S;
@@ -459,9 +479,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       dot[u] = buf16(rdo, voff_oc, (q0 + 8 * u) * os1b);
     }
   }
-  const T* Eb = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
-  const unsigned es1b = (unsigned)p.N * 128;
-  const auto re = make_rsrc(HAS_REL ? (const void*)Eb : (const void*)Qb, HAS_REL ? (unsigned)(p.R - 1) * es1b + 128 : 0u);
   if (HAS_REL) {
     if (lane < Rp)
       bias_ts[lane] = (p.bias && icol(m, lane) < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)icol(m, lane) * p.N + n] * p.tscale : 0.f;   // by column
@@ -508,9 +525,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       const float nl = -rowc[r];
 #pragma unroll
       for (int rb = 0; rb < Rp / 32; ++rb) {
-        Frag<T> ef;                     // E rows: L2-resident, only the mixed-id tiles need them
-#pragma unroll
-        for (int s = 0; s < 4; ++s) ef.v[s] = buf16(re, (unsigned)icol(m, rb * 32 + r) * es1b + 64 * h + 16 * s, 0u);   // row r <- id of column rb*32 + r
+        Frag<T> ef;                     // E rows of the table columns, from the workgroup's LDS image
+        frag_from_tile(ef, elds + rb * 4096, lane);
         f32x16 c = {0};
         c = mma_rows(ef, qf, c);
 #pragma unroll
@@ -643,7 +659,11 @@ static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
   p.red_per_plane = p.red_live = (p.S + 127) >> 7;        // one dE partial per 128-row workgroup
   const int per_bn = (p.n_chunks * p.n_gblk + 3) / 4;
   dim3 grid(p.n_band_blocks + per_bn * p.B * p.N);
-  const int lds_a = 4 * LeanLds<Rp>::kDq, lds_b = 4 * LeanLds<Rp>::kDkv;
+  const int e_img = HAS_REL ? Rp * 128 : 0;     // the workgroup's E image
+  const int lds_a = 4 * LeanLds<Rp>::kDq + e_img, lds_b = 4 * LeanLds<Rp>::kDkv + e_img;
+  if (lds_a > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_band_bf16_kernel<Rp, HAS_REL>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
   if (lds_b > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_band_bf16_kernel<Rp, HAS_REL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);

@@ -6,6 +6,6 @@ set -e
 cd "$(dirname "$0")/.."
 rev=${1:-HEAD}
 rm -rf _ab/A && mkdir -p _ab/A
-git archive "$rev" multimodal-long-transformer-2021_amd include bench.py oracle profiles/attn_fwd_traffic.json | tar -x -C _ab/A
+git archive "$rev" multimodal-long-transformer-2021_amd include bench.py oracle profiles/attn_traffic.json | tar -x -C _ab/A
 make -C _ab/A/multimodal-long-transformer-2021_amd/csrc -j8 >/dev/null
 echo "built $rev under _ab/A"
