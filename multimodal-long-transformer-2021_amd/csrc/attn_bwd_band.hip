@@ -62,10 +62,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   const int r = lane & 31, h = lane >> 5;
   constexpr int kEImg = HAS_REL ? Rp * 128 : 0;
   unsigned char* elds = smem;
-  unsigned char* wl = smem + kEImg + wave * L::kDq;
+  // per wave: T table | dRel table (row stride p.dstride floats: only columns 0 .. 2m are ever written, and with
+  // the narrow stride three workgroups fit the LDS of a CU) | K / Q tile
+  const int dstride = p.dstride;
+  const int kWave = L::kTab + 32 * dstride * 4 + 2 * L::kTile;       // + V tile
+  unsigned char* wl = smem + kEImg + wave * kWave;
   float* tab = reinterpret_cast<float*>(wl);
   float* dtab = reinterpret_cast<float*>(wl + L::kTab);
-  unsigned char* xlds = wl + 2 * L::kTab;
+  unsigned char* xlds = wl + L::kTab + 32 * dstride * 4;
+  unsigned char* vlds = xlds + L::kTile;
 
   const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
   const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
@@ -112,15 +117,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   const auto ro = make_rsrc(Ob, (unsigned)(p.S - 1) * os1b + 128);
   const auto rdo = make_rsrc(DOb, (unsigned)(p.S - 1) * os1b + 128);
   const unsigned voff_kc = (unsigned)(lane >> 3) * ks1b + (lane & 7) * 16;    // tile (coalesced) shape
-  const unsigned voff_vf = (unsigned)r * vs1b + 64 * h;                        // fragment shape
+  const unsigned voff_vc = (unsigned)(lane >> 3) * vs1b + (lane & 7) * 16;    // V rows: tile (coalesced) shape as well --
+  // fragment-shaped loads touch every 128-byte line of the tile four times (4 instructions x 32 lines)
 
   TileWalkLean w;
   if (split_item) w.set_chunk(chunk * p.chunk_tiles, min(n_tiles, (chunk + 1) * p.chunk_tiles));
   else w.set_band(p.pat, q0, p.S);
   const int n_it = w.count();
 
-  Frag<T> qf, dof, vf;
-  bf16x8 kt[4];
+  Frag<T> qf, dof;
+  bf16x8 kt[4], vt[4];
   float delta;
   {
     Frag<T> of;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
 #pragma unroll
     for (int u = 0; u < 4; ++u) kt[u] = buf16(rk, voff_kc, (k0 + 8 * u) * ks1b);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) vf.v[s] = buf16(rv, voff_vf + 16 * s, k0 * vs1b);
+    for (int u = 0; u < 4; ++u) vt[u] = buf16(rv, voff_vc, (k0 + 8 * u) * vs1b);
     float acc = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   const float lse2 = p.lse[row_id] * kLog2e;
 
   float relfn = 0.f, relfp = 0.f;
-  for (int i = lane; i < 32 * kTStride(Rp); i += 64) dtab[i] = 0.f;
+  for (int i = lane; i < 32 * dstride; i += 64) dtab[i] = 0.f;
   if (HAS_REL) {
     float* bias_ts = reinterpret_cast<float*>(xlds);
     if (lane < Rp)
@@ -178,16 +184,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   f32x16 a0 = {0}, a1 = {0};
   float far_neg_acc = 0.f, far_pos_acc = 0.f;
   const float* trow = tab + r * kTStride(Rp);
-  float* dtrow = dtab + r * kTStride(Rp);
+  float* dtrow = dtab + r * dstride;
   const int trow_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)(tab + r * kTStride(Rp));
   const uint32_t drop_base = drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q);
 
   for (int it = 0; it < n_it; ++it) {
     const int k0 = w.at(it) * 32;
     tile_to_lds(xlds, kt, lane);
+    tile_to_lds(vlds, vt, lane);
     wave_lds_sync();
-    Frag<T> kf;
+    Frag<T> kf, vf;
     frag_from_tile(kf, xlds, lane);
+    frag_from_tile(vf, vlds, lane);
     f32x16 c = {0}, dp = {0};
     c = mma_rows(kf, qf, c);      // S^T  [key x q]
     dp = mma_rows(vf, dof, dp);   // dP^T [key x q]
@@ -196,7 +204,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
 #pragma unroll
       for (int u = 0; u < 4; ++u) kt[u] = buf16(rk, voff_kc, (k1 + 8 * u) * ks1b);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) vf.v[s] = buf16(rv, voff_vf + 16 * s, k1 * vs1b);
+      for (int u = 0; u < 4; ++u) vt[u] = buf16(rv, voff_vc, (k1 + 8 * u) * vs1b);
+    } else if (HAS_REL && !split_item) {
+      // last tile: the K staging registers are free -- fetch this block's Q rows in tile shape for the dE
+      // contraction of the epilogue now, so that the wave does not end on an exposed memory round trip
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kt[u] = buf16(rq, (unsigned)(lane >> 3) * qs1b + (lane & 7) * 16, (unsigned)(q0 + 8 * u) * qs1b);
     }
     const bool no_gkey = p.pat.ng == 0 || k0 + 31 < p.pat.g0 || k0 >= p.pat.g0 + p.pat.ng;
     const TileClass tc = classify_tile(q0, k0, p.S, valid_len, W, m, ignore_band, no_gkey);
@@ -309,7 +322,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     float* pt = p.part_dtab + slot * (32 * Rp);
     for (int i = lane; i < 32 * Rp; i += 64) {
       const int rr = i / Rp, id = i - rr * Rp;
-      pt[i] = dtab[rr * kTStride(Rp) + tcol(1, m, id)];
+      const int col = tcol(1, m, id);
+      pt[i] = col < dstride ? dtab[rr * dstride + col] : 0.f;
     }
     return;
   }
@@ -322,8 +336,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     for (int rb = 0; rb < Rp / 32; ++rb) {
       float vals[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) vals[i] = dtrow[rb * 32 + kap(i, h)];
-      mma_xt_hilo(a0, a1, VTile<T>{}, elds + rb * 4096, vals, lane);
+      for (int i = 0; i < 16; ++i) vals[i] = rb * 32 + kap(i, h) < dstride ? dtrow[rb * 32 + kap(i, h)] : 0.f;
+      mma_xt(a0, a1, VTile<T>{}, elds + rb * 4096, vals, lane);
     }
   }
   if (q_ok && !(p.skip_global && is_global(p.pat, q))) {
@@ -340,47 +354,69 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   }
   if (!HAS_REL) return;
 
-  // (2) the workgroup's share of dE^T[d x id] = Q^T . dRel and dbias[id]: every wave leaves its Q tile next
-  //     to its dRel table in LDS, then wave 0 contracts all (up to) 128 query rows -- one partial per
-  //     workgroup instead of one per wave for the fixed-order reduce (K4c reads 4x less).
-  {
-    bf16x8 qt[4];
+  // (2) the workgroup's share of dE^T[d x id] = Q^T . dRel and dbias[id] (one partial per workgroup for the
+  //     fixed-order reduce K4c).  Every wave contracts ITS 32 query rows at once (its Q tile and dRel table are
+  //     in its own LDS), parks the 64 x 32 result over its -- now dead -- tables, and after one workgroup
+  //     barrier each wave adds a quarter of the ids over the (up to) four parked partials, in wave order, and
+  //     stores it.  Before, wave 0 did all of this for the four waves behind the barrier: 14 of the kernel's
+  //     93 us (tile-cap / no-dE ablations, profiles/r02 notes in DESIGN.md).
+  if (n_it == 0) {             // (no tile visited: nothing was prefetched)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) qt[u] = buf16(rq, (unsigned)(lane >> 3) * qs1b + (lane & 7) * 16, (unsigned)(q0 + 8 * u) * qs1b);
-    tile_to_lds(xlds, qt, lane);
+    for (int u = 0; u < 4; ++u) kt[u] = buf16(rq, (unsigned)(lane >> 3) * qs1b + (lane & 7) * 16, (unsigned)(q0 + 8 * u) * qs1b);
   }
-  __syncthreads();                 // waves past the end of the sequence have exited and are not waited for
-  if (wave != 0) return;
-  float* pe = p.part_red + (long)band_wg * (Rp * 64 + Rp);
+  tile_to_lds(xlds, kt, lane);
+  wave_lds_sync();
+  constexpr int kParkBias = Rp == 32 ? 8192 : 2 * L::kTab;      // byte offset of the parked bias sums inside the wave's LDS
 #pragma unroll
   for (int rb = 0; rb < Rp / 32; ++rb) {
     const int id = rb * 32 + r;
     const int col = tcol(1, m, id);
     f32x16 e0 = {0}, e1 = {0};
     float bsum = 0.f;
-    for (int w2 = 0; w2 < 4; ++w2) {
-      const int q0w = q0 + 32 * w2;
-      if (q0w >= p.S) break;
-      const float* dtab_w = reinterpret_cast<const float*>(smem + kEImg + w2 * L::kDq + L::kTab);
-      const unsigned char* xlds_w = smem + kEImg + w2 * L::kDq + 2 * L::kTab;
-      float vals[16];
+    float vals[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int qq = q0w + kap(i, h);
-        const bool use = id < p.R && qq < p.S && !(p.skip_global && is_global(p.pat, qq));
-        vals[i] = use ? dtab_w[kap(i, h) * kTStride(Rp) + col] : 0.f;
-        bsum += vals[i];
-      }
-      mma_xt_hilo(e0, e1, VTile<T>{}, xlds_w, vals, lane);
+    for (int i = 0; i < 16; ++i) {
+      const int qq = q0 + kap(i, h);
+      const bool use = id < p.R && qq < p.S && !(p.skip_global && is_global(p.pat, qq));
+      vals[i] = (use && col < dstride) ? dtab[kap(i, h) * dstride + col] : 0.f;
+      bsum += vals[i];
     }
+    mma_xt(e0, e1, VTile<T>{}, xlds, vals, lane);
     bsum = half_sum(bsum);
-    float* row = pe + (long)id * 64;
+    wave_lds_sync();               // this block's table and tile reads are done: the park may overwrite them
+    float* park = reinterpret_cast<float*>(wl + rb * L::kTab) + r * 64;
 #pragma unroll
     for (int gi = 0; gi < 4; ++gi) {
-      *reinterpret_cast<f32x4*>(row + 8 * gi + 4 * h) = f32x4{e0[4 * gi], e0[4 * gi + 1], e0[4 * gi + 2], e0[4 * gi + 3]};
-      *reinterpret_cast<f32x4*>(row + 32 + 8 * gi + 4 * h) = f32x4{e1[4 * gi], e1[4 * gi + 1], e1[4 * gi + 2], e1[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(park + 8 * gi + 4 * h) = f32x4{e0[4 * gi], e0[4 * gi + 1], e0[4 * gi + 2], e0[4 * gi + 3]};
+      *reinterpret_cast<f32x4*>(park + 32 + 8 * gi + 4 * h) = f32x4{e1[4 * gi], e1[4 * gi + 1], e1[4 * gi + 2], e1[4 * gi + 3]};
     }
-    if (h == 0) pe[Rp * 64 + id] = bsum;
+    if (h == 0) reinterpret_cast<float*>(wl + kParkBias)[id] = bsum;
+  }
+  __syncthreads();                 // waves past the end of the sequence have exited and are not waited for
+  {
+    const int q0_wg = q0 - 32 * wave;
+    float* pe = p.part_red + (long)band_wg * (Rp * 64 + Rp);
+    const int n_live = min(4, (p.S - q0_wg + 31) >> 5);               // waves of this workgroup that exist
+    const int d0 = (lane & 7) * 8;
+    for (int g = wave; g < 4; g += n_live) {                          // id groups of 8, dealt over the live waves
+      const int idl = 8 * g + (lane >> 3);                            // this lane: one id of the group, 8 head dims
+#pragma unroll
+      for (int rb = 0; rb < Rp / 32; ++rb) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        float bs = 0.f;
+        for (int w2 = 0; w2 < n_live; ++w2) {
+          const unsigned char* wl2 = smem + kEImg + w2 * kWave;
+          const float* src = reinterpret_cast<const float*>(wl2 + rb * L::kTab) + idl * 64 + d0;
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(src), x1 = *reinterpret_cast<const f32x4*>(src + 4);
+          s0 += x0; s1 += x1;
+          if (lane < 8) bs += reinterpret_cast<const float*>(wl2 + kParkBias)[rb * 32 + 8 * g + lane];
+        }
+        float* row = pe + (long)(rb * 32 + idl) * 64 + d0;
+        *reinterpret_cast<f32x4*>(row) = s0;
+        *reinterpret_cast<f32x4*>(row + 4) = s1;
+        if (lane < 8) pe[Rp * 64 + rb * 32 + 8 * g + lane] = bs;
+      }
+    }
   }
 }
 
@@ -660,7 +696,8 @@ static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
   const int per_bn = (p.n_chunks * p.n_gblk + 3) / 4;
   dim3 grid(p.n_band_blocks + per_bn * p.B * p.N);
   const int e_img = HAS_REL ? Rp * 128 : 0;     // the workgroup's E image
-  const int lds_a = 4 * LeanLds<Rp>::kDq + e_img, lds_b = 4 * LeanLds<Rp>::kDkv + e_img;
+  p.dstride = (Rp == 32 && 2 * p.pat.m + 1 <= 27) ? 28 : kTStride(Rp);     // 27 r: conflict-free diagonal stores
+  const int lds_a = 4 * (LeanLds<Rp>::kTab + 32 * p.dstride * 4 + 2 * LeanLds<Rp>::kTile) + e_img, lds_b = 4 * LeanLds<Rp>::kDkv + e_img;
   if (lds_a > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_band_bf16_kernel<Rp, HAS_REL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);

@@ -46,6 +46,7 @@ struct BwdParams {
   float *drel_emb, *drel_bias;        // outputs [R,N,64], [R,N] fp32
   int drel_accum;                     // != 0: add to them instead of overwriting
   int red_per_plane, red_live;        // dE partials per (b,n) plane in part_red: slots, and how many of them are written
+  int dstride;                        // lean dQ kernel: row stride (floats) of the per-wave dRel table in LDS
   int comb_in_next;                   // lean path: dQ combine rides in the dK/dV launch, dK/dV combine in the dE reduce
   int B, S, N, R, Rp;
   long qs[3], ks[3], vs[3], os[3];    // q/dq, k/dk, v/dv, out/dout
