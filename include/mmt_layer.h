@@ -130,6 +130,27 @@ int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, const void* 
                               const void* x, int64_t ldx, int32_t M, int32_t N, int64_t K,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* Up to eight such products in ONE launch -- the weight gradients of the four Dense layers of one or two encoder blocks
+ * (`tape.gradient`, src/tasks/pretraining.py:292-296), which contract the same K = B*S rows.  Alone, the small
+ * products need a deep split of K to fill the chip and write one fp32 slab per slice; together two slices
+ * suffice for one block (108 tiles at BERT-base dims: 4x less slab traffic) and for two blocks K is not split
+ * at all: every tile belongs to one workgroup, which adds it into dw with plain stores (no slabs, no reduce).  Every problem needs M % 256 == 0,
+ * N % 256 == 0; K % 64 == 0; the workspace (mmt_wgrad_group_workspace_bytes) is required.  dbias may be NULL
+ * per problem.  Results are bitwise those of a fixed-order sum over the slices. */
+typedef struct mmt_wgrad_problem {
+  float* dw;        /* [M, N] fp32, row stride ldw, accumulated into */
+  int64_t ldw;
+  float* dbias;     /* [M] fp32 += column sums of dy, or NULL */
+  const void* dy;   /* [K, M] bf16, row stride ldy */
+  int64_t ldy;
+  const void* x;    /* [K, N] bf16, row stride ldx */
+  int64_t ldx;
+  int32_t M, N;
+} mmt_wgrad_problem;
+size_t mmt_wgrad_group_workspace_bytes(int32_t n, const mmt_wgrad_problem* problems, int64_t K);
+int mmt_wgrad_grouped(int32_t n, const mmt_wgrad_problem* problems, int64_t K, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Embedding assembly of MmtEncoder.call (src/modeling/models/mmt_encoder.py:189-218):
  *   we  = Dropout(LayerNorm_eps(WordEmb[word_ids]))          LN + dropout on the WORD embeddings only

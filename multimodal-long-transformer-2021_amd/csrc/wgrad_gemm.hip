@@ -217,25 +217,21 @@ constexpr int kDmaStageBytes = 2 * 8 * 4096;
 
 __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-__global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) {
+// XCD-aware order: blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8); XCD x takes the
+// x-th contiguous range of the list ordered (split-K slice, tile), so that the workgroups sharing one L2 read
+// the same K rows and mostly the same dy / x column slabs (each slab ~once per L2 instead of once per
+// workgroup -- the L2-miss traffic, not the MFMA rate, bounded this kernel).
+__device__ __forceinline__ int xcd_list_index() {
+  const int nwg = gridDim.x, b = blockIdx.x, x = b & 7;
+  const int base = nwg >> 3, rem = nwg & 7;                       // XCD y holds base + (y < rem) blocks
+  return x * base + min(x, rem) + (b >> 3);
+}
+
+__device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, int ks, int tm, int tn) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int h = lane >> 5, li = lane & 15, cb = (lane >> 4) & 1, r = lane & 31;
-  // XCD-aware order: blocks are dealt round-robin over the 8 XCDs (block b -> XCD b % 8); XCD x takes the
-  // x-th contiguous range of the list ordered (split-K slice, row tile, column tile), so that the workgroups
-  // sharing one L2 read the same K rows and mostly the same dy / x column slabs (each slab ~once per L2
-  // instead of once per workgroup -- the L2-miss traffic, not the MFMA rate, bounded this kernel).
-  int ks, tm, tn;
-  {
-    const int nwg = gridDim.x, b = blockIdx.x, x = b & 7;
-    const int base = nwg >> 3, rem = nwg & 7;                       // XCD y holds base + (y < rem) blocks
-    const int L = x * base + min(x, rem) + (b >> 3);
-    const int tiles = p.tiles_n * p.tiles_m;
-    ks = L / tiles;
-    const int t = L - ks * tiles;
-    tm = t / p.tiles_n; tn = t - tm * p.tiles_n;
-  }
   const int m0 = tm * 256, n0 = tn * 256;
   const int k_begin = ks * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
@@ -354,6 +350,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) 
 #pragma unroll
       for (int g = 0; g < 16; ++g) t += red[g * 256 + tid];
       if (p.bias_part) p.bias_part[(long)ks * p.M + m0 + tid] = t;
+      else if (p.k_per_split >= p.K) p.dbias[m0 + tid] += t;          // one slice: this workgroup owns the rows
       else atomicAdd(p.dbias + m0 + tid, t);
     }
   }
@@ -370,6 +367,18 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) 
     return;
   }
   float* out = p.dw + (long)(m0 + wm * 64) * p.ldw + n0 + wn * 128 + r;
+  if (p.k_per_split >= p.K) {      // one slice of K: the tile belongs to this workgroup alone -- plain read-add-store
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float* o = out + (long)(32 * a + kap(i, h)) * p.ldw + 32 * b;
+          *o += acc[a][b][i];
+        }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -377,6 +386,35 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) 
 #pragma unroll
       for (int i = 0; i < 16; ++i)
         atomicAdd(out + (long)(32 * a + kap(i, h)) * p.ldw + 32 * b, acc[a][b][i]);
+}
+
+__global__ __launch_bounds__(512, 2) void wgrad_dma_kernel(const WgradParams p) {
+  const int L = xcd_list_index();
+  const int tiles = p.tiles_n * p.tiles_m;
+  const int ks = L / tiles, t = L - ks * tiles;
+  const int tm = t / p.tiles_n;
+  wgrad_dma_body(p, ks, tm, t - tm * p.tiles_n);
+}
+
+// Up to eight weight-gradient products in ONE launch (the four Dense layers of one or two encoder blocks: same K rows,
+// same 256 x 256 tiles).  Alone, a 768 x 768 product has 9 tiles and needs a 24-way split of K to fill the
+// chip -- 24 fp32 slabs written and read back for one gradient; together the block's four products have 108
+// tiles, two K slices fill the chip, and the slab traffic falls from ~230 MB to ~57 MB per block.
+struct WgradGroup {
+  WgradParams p[8];
+  int tiles_end[8];      // running tile count
+  int n, tiles_total;
+};
+__global__ __launch_bounds__(512, 2) void wgrad_dma_group_kernel(const WgradGroup g) {
+  const int L = xcd_list_index();
+  const int ks = L / g.tiles_total;
+  int t = L - ks * g.tiles_total;
+  int j = 0;
+  while (j + 1 < g.n && t >= g.tiles_end[j]) ++j;
+  if (j > 0) t -= g.tiles_end[j - 1];
+  const WgradParams p = g.p[j];
+  const int tm = t / p.tiles_n;
+  wgrad_dma_body(p, ks, tm, t - tm * p.tiles_n);
 }
 
 // dw[m][n] += sum_s slabs[s][m][n]   (fixed order: bitwise reproducible)
@@ -484,4 +522,87 @@ extern "C" int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, c
     e = hipGetLastError();
   }
   return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_wgrad_accumulate: %s", hipGetErrorString(e));
+}
+
+// ---- grouped launch (see wgrad_dma_group_kernel) --------------------------------------------------------
+namespace {
+bool group_ok(int32_t n, const mmt_wgrad_problem* pr, int64_t K) {
+  if (n < 1 || n > 8 || !pr || K <= 0 || (K % 64)) return false;
+  for (int i = 0; i < n; ++i) {
+    const mmt_wgrad_problem& q = pr[i];
+    if (!q.dw || !q.dy || !q.x || q.M <= 0 || q.N <= 0 || (q.M % 256) || (q.N % 256)) return false;
+    if ((q.ldy % 8) || (q.ldx % 8) || q.ldy < q.M || q.ldx < q.N || q.ldw < q.N || (q.ldw % 4)) return false;
+    if (((uintptr_t)q.dy & 15) || ((uintptr_t)q.x & 15) || ((uintptr_t)q.dw & 15)) return false;
+  }
+  return true;
+}
+// split-K factor and rows per slice of a group with `tiles` 256 x 256 tiles in all
+void group_split(int tiles, int64_t K, int& split, int& kps) {
+  const int cus = g_cu_budget.load(std::memory_order_relaxed);
+  split = cus / tiles;
+  const int max_split = (int)((K + 255) / 256);
+  if (split > max_split) split = max_split;
+  if (split < 1) split = 1;
+  kps = (int)(((K + split - 1) / split + 63) / 64 * 64);
+  split = (int)((K + kps - 1) / kps);
+}
+}  // namespace
+
+extern "C" size_t mmt_wgrad_group_workspace_bytes(int32_t n, const mmt_wgrad_problem* problems, int64_t K) {
+  if (!group_ok(n, problems, K)) return 0;
+  int tiles = 0;
+  size_t elems = 0;
+  for (int i = 0; i < n; ++i) { tiles += (problems[i].M / 256) * (problems[i].N / 256); elems += (size_t)problems[i].M * problems[i].N + problems[i].M; }
+  int split, kps;
+  group_split(tiles, K, split, kps);
+  return split > 1 ? (size_t)split * elems * sizeof(float) : 0;      // an unsplit K needs no slabs
+}
+
+extern "C" int mmt_wgrad_grouped(int32_t n, const mmt_wgrad_problem* problems, int64_t K, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  if (!group_ok(n, problems, K))
+    return mmt::fail(MMT_E_UNSUPPORTED, "mmt_wgrad_grouped: needs 1..8 problems with M %% 256 == 0, N %% 256 == 0, K %% 64 == 0, 16-byte aligned operands");
+  const size_t need = mmt_wgrad_group_workspace_bytes(n, problems, K);
+  if (need > 0 && (!workspace || workspace_bytes < need)) return mmt::fail(MMT_E_WORKSPACE, "mmt_wgrad_grouped: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+  mmt::WgradGroup g;
+  g.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += (problems[i].M / 256) * (problems[i].N / 256);
+  int split, kps;
+  group_split(tiles, K, split, kps);
+  float* ws = (float*)workspace;
+  int run = 0;
+  for (int i = 0; i < 8; ++i) {
+    const mmt_wgrad_problem& q = problems[i < n ? i : n - 1];
+    mmt::WgradParams& p = g.p[i];
+    p.dy = (const __bf16*)q.dy; p.x = (const __bf16*)q.x; p.dw = q.dw;
+    p.ldy = q.ldy; p.ldx = q.ldx; p.ldw = q.ldw; p.M = q.M; p.N = q.N; p.K = (int)K;
+    p.tiles_n = q.N / 256; p.tiles_m = q.M / 256; p.k_per_split = kps;
+    p.dbias = q.dbias;
+    p.slabs = nullptr; p.bias_part = nullptr;
+    if (i < n) {
+      if (split > 1) {
+        p.slabs = ws; ws += (size_t)split * q.M * q.N;
+        if (q.dbias) { p.bias_part = ws; }
+        ws += (size_t)split * q.M;
+      }
+      run += p.tiles_n * p.tiles_m;
+    }
+    g.tiles_end[i] = run;
+  }
+  g.tiles_total = tiles;
+  hipStream_t st = (hipStream_t)stream;
+  const int lds = 2 * mmt::kDmaStageBytes;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmt::wgrad_dma_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipLaunchKernelGGL(mmt::wgrad_dma_group_kernel, dim3(tiles * split), dim3(512), lds, st, g);
+  hipError_t e = hipGetLastError();
+  for (int i = 0; i < n && e == hipSuccess && split > 1; ++i) {
+    const mmt::WgradParams& p = g.p[i];
+    long blocks = ((long)p.M * p.N / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(mmt::wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.dw, (long)p.ldw, p.slabs, split, p.M, p.N,
+                       p.bias_part ? p.dbias : nullptr, p.bias_part);
+    e = hipGetLastError();
+  }
+  return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_wgrad_grouped: %s", hipGetErrorString(e));
 }

@@ -24,7 +24,7 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
            'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_colsum_reduce', 'mmt_accumulate_grad', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
-           'mmt_wgrad_bias_accumulate', 'mmt_wgrad_workspace_bytes', 'mmt_wgrad_set_cu_budget', 'mmt_embed_fwd', 'mmt_embed_bwd',
+           'mmt_wgrad_bias_accumulate', 'mmt_wgrad_grouped', 'mmt_wgrad_group_workspace_bytes', 'mmt_wgrad_workspace_bytes', 'mmt_wgrad_set_cu_budget', 'mmt_embed_fwd', 'mmt_embed_bwd',
            'mmt_embed_workspace_bytes', 'mmt_xent_fwd', 'mmt_xent_bwd', 'mmt_ffn_gelu_gemm', 'mmt_ffn_dgelu_gemm', 'mmt_ffn_set_cu_budget')
 
 
@@ -64,6 +64,12 @@ class AdamwDesc(ctypes.Structure):
               ('beta2', ctypes.c_float), ('eps', ctypes.c_float), ('bias_correction1', ctypes.c_float),
               ('bias_correction2', ctypes.c_float), ('zero_grad', ctypes.c_int32),
               ('reserved', ctypes.c_int32)]
+
+
+class WgradProblem(ctypes.Structure):
+  _fields_ = [('dw', ctypes.c_void_p), ('ldw', ctypes.c_int64), ('dbias', ctypes.c_void_p), ('dy', ctypes.c_void_p),
+              ('ldy', ctypes.c_int64), ('x', ctypes.c_void_p), ('ldx', ctypes.c_int64), ('M', ctypes.c_int32),
+              ('N', ctypes.c_int32)]
 
 
 class MmtError(RuntimeError):
@@ -133,6 +139,11 @@ def lib() -> ctypes.CDLL:
   L.mmt_wgrad_bias_accumulate.restype = ctypes.c_int
   L.mmt_wgrad_bias_accumulate.argtypes = [vp, ctypes.c_int64, vp, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int64, vp, ctypes.c_size_t, vp]
+  wp = ctypes.POINTER(WgradProblem)
+  L.mmt_wgrad_group_workspace_bytes.restype = ctypes.c_size_t
+  L.mmt_wgrad_group_workspace_bytes.argtypes = [ctypes.c_int32, wp, ctypes.c_int64]
+  L.mmt_wgrad_grouped.restype = ctypes.c_int
+  L.mmt_wgrad_grouped.argtypes = [ctypes.c_int32, wp, ctypes.c_int64, vp, ctypes.c_size_t, vp]
   ed = ctypes.POINTER(EmbedDesc)
   L.mmt_embed_fwd.restype = ctypes.c_int
   L.mmt_embed_fwd.argtypes = [ed] + [vp] * 13

@@ -360,12 +360,16 @@ def _side_stream(device):
 
 def wait_side_streams():
   """The current stream waits for everything enqueued on the weight-gradient stream(s) so far."""
+  for device in list(_wg_pending):
+    _flush_wgrad(device)
   for device in _side_pending:
     torch.cuda.current_stream(device).wait_stream(_SIDE[device])
 
 
 def _join_side_streams():
   """Engine callback at the end of backward: the current stream waits for the weight-gradient stream."""
+  for device in list(_wg_pending):
+    _flush_wgrad(device)
   for device in list(_side_pending):
     torch.cuda.current_stream(device).wait_stream(_SIDE[device])
   _side_pending.clear()
@@ -385,9 +389,69 @@ def side_stream_ok(*params) -> bool:
   return not any(getattr(p, '_mmt_grad_ready_hooks', ()) for p in params if p is not None)
 
 
+def _wgrad_groupable(dw, dy, x, dbias) -> bool:
+  K, M = dy.shape
+  N = x.shape[1]
+  return (dw.is_cuda and dw.dtype == torch.float32 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+          and dw.shape == (M, N) and x.shape[0] == K and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K > 0
+          and dw.stride(1) == 1 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 8 == 0
+          and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and dw.stride(0) % 4 == 0
+          and dw.data_ptr() % 16 == 0
+          and (dbias is None or (dbias.dtype == torch.float32 and dbias.is_contiguous() and dbias.numel() == M
+                                 and dbias.device == dw.device)))
+
+
+# Weight-gradient products waiting to be launched together (per device): the four Dense layers of an encoder
+# block contract the same rows, and ONE grouped launch (`mmt_wgrad_grouped`) needs a 2-way instead of a 6- to
+# 24-way split of K -- 4x less fp32 slab traffic (~0.2 GB per block).  They are off the critical path of
+# backward (side stream), so waiting for the block's last product costs nothing.
+_WG_GROUP = int(os.environ.get('MMT_WGRAD_GROUP', '4'))
+_wg_pending = {}
+
+
+def _flush_wgrad(device) -> None:
+  items = _wg_pending.pop(device, None)
+  if not items:
+    return
+  side = _side_stream(device)
+  side.wait_stream(torch.cuda.current_stream(device))     # every queued dy / x is final on the main stream
+  L = _lib.lib()
+  with torch.cuda.stream(side):
+    if len(items) == 1:
+      dw, dy, x, dbias = items[0]
+      if not wgrad_accumulate_(dw, dy, x, dbias):
+        raise RuntimeError('mmt_wgrad_accumulate refused a shape _wgrad_groupable admitted')
+    else:
+      K = items[0][1].shape[0]
+      arr = (_lib.WgradProblem * len(items))()
+      for q, (dw, dy, x, dbias) in zip(arr, items):
+        q.dw, q.ldw, q.dbias = dw.data_ptr(), dw.stride(0), (None if dbias is None else dbias.data_ptr())
+        q.dy, q.ldy, q.x, q.ldx = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+        q.M, q.N = dy.shape[1], x.shape[1]
+      ws = _wgrad_ws(device, max(16, L.mmt_wgrad_group_workspace_bytes(len(items), arr, K)))
+      with torch.cuda.device(device):
+        _lib.check(L.mmt_wgrad_grouped(len(items), arr, K, ws.data_ptr(), ws.numel(), side.cuda_stream))
+  for _, dy, x, _ in items:
+    dy.record_stream(side)
+    x.record_stream(side)
+
+
 def wgrad_accumulate_side_(dw, dy, x, dbias=None) -> bool:
-  """`wgrad_accumulate_` enqueued on the side stream (inside a backward pass only)."""
+  """`wgrad_accumulate_` on the side stream (inside a backward pass only).  Products the grouped kernel can take
+  are queued and launched together, `MMT_WGRAD_GROUP` (4) at a time or when backward ends / somebody waits for
+  the side stream; the others go out at once."""
   device = dw.device
+  if _WG_GROUP > 1 and _wgrad_groupable(dw, dy, x, dbias):
+    q = _wg_pending.setdefault(device, [])
+    if q and q[0][1].shape[0] != dy.shape[0]:        # another K: cannot share the slices
+      _flush_wgrad(device)
+      q = _wg_pending.setdefault(device, [])
+    q.append((dw, dy, x, dbias))
+    _side_stream(device)
+    _mark_side(device)
+    if len(q) >= _WG_GROUP:
+      _flush_wgrad(device)
+    return True
   side = _side_stream(device)
   main = torch.cuda.current_stream(device)
   side.wait_stream(main)

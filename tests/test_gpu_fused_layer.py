@@ -362,3 +362,48 @@ def test_ffn_gemm_cu_budget_changes_the_schedule_not_the_result():
   for o in outs[1:]:
     assert all(torch.equal(p, q) for p, q in zip(o, outs[0]))
   assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize('blocks', [1, 2], ids=['one-block-split-k', 'two-blocks-unsplit'])
+def test_grouped_weight_gradients_match_fp32_reference(blocks):
+  """mmt_wgrad_grouped: the four weight gradients of one / two encoder blocks (BERT-base feature sizes) in one
+  launch, half of them with the bias gradient, accumulated into non-zero fp32 buffers -- against fp32 matmuls, and
+  bit for bit against a second run (fixed-order split-K sums; with two blocks K is not split and every tile is
+  added by its one workgroup with plain stores)."""
+  from mmt_amd import _lib, fused
+  L = _lib.lib()
+  torch.manual_seed(0)
+  K = 2048
+  shapes = [(768, 3072, False), (3072, 768, True), (768, 768, False), (2304, 768, True)] * blocks   # (M, N, bias)
+  n = len(shapes)
+  outs = []
+  for rep in range(2):
+    torch.manual_seed(1)
+    probs, keep, refs = (_lib.WgradProblem * n)(), [], []
+    for q, (M, N, with_b) in zip(probs, shapes):
+      dy = torch.randn(K, M, device='cuda', dtype=torch.bfloat16)
+      x = torch.randn(K, N, device='cuda', dtype=torch.bfloat16)
+      dw = torch.randn(M, N, device='cuda')
+      db = torch.randn(M, device='cuda') if with_b else None
+      refs.append((dw + dy.float().t() @ x.float(), None if db is None else db + dy.float().sum(0)))
+      q.dw, q.ldw, q.dbias = dw.data_ptr(), N, (None if db is None else db.data_ptr())
+      q.dy, q.ldy, q.x, q.ldx, q.M, q.N = dy.data_ptr(), M, x.data_ptr(), N, M, N
+      keep.append((dy, x, dw, db))
+    need = L.mmt_wgrad_group_workspace_bytes(n, probs, K)
+    assert (need > 0) == (blocks == 1)            # two blocks: 216 tiles fill the chip without splitting K
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device='cuda')
+    _lib.check(L.mmt_wgrad_grouped(n, probs, K, ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for (dy, x, dw, db), (rw, rb) in zip(keep, refs):
+      assert float((dw - rw).abs().max()) / float(rw.abs().max()) < 1e-5
+      if db is not None:
+        assert float((db - rb).abs().max()) / float(rb.abs().max()) < 1e-5
+    outs.append([t[2].clone() for t in keep] + [t[3].clone() for t in keep if t[3] is not None])
+  for a, b in zip(*outs):
+    assert torch.equal(a, b)
+  # refusals: a shape the 256 x 256 kernel cannot tile, a missing workspace
+  bad = (_lib.WgradProblem * 1)()
+  bad[0].M, bad[0].N = 128, 256
+  assert L.mmt_wgrad_group_workspace_bytes(1, bad, K) == 0
+  if blocks == 1:
+    assert L.mmt_wgrad_grouped(n, probs, K, None, 0, None) == -3          # MMT_E_WORKSPACE
