@@ -75,6 +75,7 @@ mmt::PatternDev make_pattern(const mmt_mask_desc& m, int S) {
   p.id_mode = m.id_mode;
   p.m = m.max_dist;
   p.P = m.patches_per_row > 0 ? m.patches_per_row : 1;
+  p.magicP = (unsigned)((1ull << 32) / (unsigned)p.P) + 1u;      // exact for x * P < 2^32: x < S (checked: S * stride < 2^31, P <= S)
   p.r = m.core_layers;
   p.I = m.id_mode == MMT_IDS_2D ? m.patches_per_row * m.patches_per_row : 0;
   p.image_part = m.patches_per_row * m.patches_per_row + 8 + 2 * m.max_dist + 1;

@@ -35,6 +35,7 @@ struct PatternDev {
   int m;           // relative_pos_max_distance
   int P, r;        // patches per row, core layers (2-D)
   int I;           // P*P image positions (2-D), 0 otherwise
+  unsigned magicP; // floor(2^32 / P) + 1: x / P == umulhi(x, magicP) for x * P < 2^32 (no integer-division sequence per element)
   int image_part;  // P*P + 8 + 2m + 1   (feature_utils.py:78-79)
   int text_part;   // image_part + 1     (feature_utils.py:82)
 };
@@ -68,8 +69,8 @@ __device__ __forceinline__ int rel_id(const PatternDev& p, int q, int k) {
   // id_mode == 2  (feature_utils.py:172-184)
   const bool qi = q < p.I, ki = k < p.I;
   if (qi && ki) {
-    const int xq = q / p.P, yq = q - xq * p.P;
-    const int xk = k / p.P, yk = k - xk * p.P;
+    const int xq = (int)__umulhi((unsigned)q, p.magicP), yq = q - xq * p.P;
+    const int xk = (int)__umulhi((unsigned)k, p.magicP), yk = k - xk * p.P;
     return id_2d(xk - xq, yk - yq, p.r);
   }
   if (qi) return p.text_part;
