@@ -86,6 +86,17 @@ int mmt_bias_gelu_bwd(const mmt_rows_desc* desc, const void* dy, const void* u, 
  * g_dtype: MMT_F32 | MMT_BF16; acc must be 16-byte aligned, g 8-byte aligned. */
 int mmt_accumulate_grad(float* acc, const void* g, int32_t g_dtype, int64_t n, void* stream);
 
+/* Global-norm clip factor of the gradient slabs (`optimizer_config.gradient_clip_norm`, the reference's trainer
+ * config src/configs/pretraining_experiments.py:24-47, applied after the all-reduce of pretraining.py:273):
+ *   norm = pending_scale * sqrt(sum over all slabs of g^2),   *scale_out = min(1, max_norm / (norm + 1e-6)) * pending_scale
+ * in one streaming pass + a fixed-order sum of 2048 per-block partials (bitwise reproducible).  `pending_scale` is a
+ * factor (e.g. 1/replicas) the slabs have not been multiplied with yet; `scale_out` (device float) is what
+ * mmt_adamw_step takes as grad_scale; `norm_out` (device float) may be NULL.  Up to 16 slabs, each 16-byte aligned
+ * with a multiple of 4 elements; workspace: 2048 floats. */
+int mmt_grad_clip_scale(int32_t n_slabs, const float* const* slabs, const int64_t* sizes, float max_norm,
+                        float pending_scale, float* scale_out, float* norm_out, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* One AdamW step over a flat parameter slab (the optimizer of the reference's trainer config,
  * src/configs/pretraining_experiments.py:24-47: adamw, weight_decay_rate 0.01 with the
  * LayerNorm/bias exclusion list, applied after the gradient all-reduce of

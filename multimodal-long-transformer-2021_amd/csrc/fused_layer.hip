@@ -340,6 +340,58 @@ __global__ __launch_bounds__(256) void accumulate_grad_kernel(float* acc, const 
   }
 }
 
+// Global gradient norm + clip factor (`optimizer_config.gradient_clip_norm`, applied to the all-reduced gradients
+// before AdamW): one streaming pass over the flat fp32 gradient slabs (16 bytes per lane, 4 loads in flight), a
+// partial sum of squares per block, and a one-block kernel that adds the partials in a fixed order and writes
+//   scale = min(1, max_norm / (pending * sqrt(sum) + 1e-6)) * pending
+// (pending = a mean over replicas that has not been applied to the slabs yet) as the device scalar AdamW reads.
+constexpr int kMaxNormSlabs = 16, kNormBlocks = 2048;
+struct NormSlabs {
+  const float* ptr[kMaxNormSlabs];
+  long n4[kMaxNormSlabs];       // float4 elements
+  int n;
+};
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const NormSlabs a, float* partials) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int sidx = 0; sidx < a.n; ++sidx) {
+    const f32x4* x = reinterpret_cast<const f32x4*>(a.ptr[sidx]);
+    const long n4 = a.n4[sidx], stride = (long)gridDim.x * 256;
+    long c = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; c + 3 * stride < n4; c += 4 * stride) {
+      const f32x4 v0 = x[c], v1 = x[c + stride], v2 = x[c + 2 * stride], v3 = x[c + 3 * stride];
+      acc += (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
+      acc += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
+      acc += (v2[0] * v2[0] + v2[1] * v2[1]) + (v2[2] * v2[2] + v2[3] * v2[3]);
+      acc += (v3[0] * v3[0] + v3[1] * v3[1]) + (v3[2] * v3[2] + v3[3] * v3[3]);
+    }
+    for (; c < n4; c += stride) {
+      const f32x4 v = x[c];
+      acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void clip_scale_kernel(const float* partials, float max_norm, float pending,
+                                                         float* scale_out, float* norm_out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < kNormBlocks; i += 256) acc += (double)partials[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt((red[0] + red[1]) + (red[2] + red[3])) * pending;
+    if (norm_out) *norm_out = norm;
+    *scale_out = fminf(max_norm / (norm + 1e-6f), 1.f) * pending;
+  }
+}
+
 // AdamW over a flat slab; one block = one 1024-element chunk (4 elements per thread).
 struct AdamwParams {
   float lr, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2;
@@ -551,6 +603,27 @@ int mmt_colsum_reduce(const mmt_rows_desc* d, int32_t kind, const void* ws, floa
   if ((ksets >= 2 && !o1) || (ksets >= 3 && !o2)) return lfail(MMT_E_INVALID, "mmt_colsum_reduce: output missing");
   hipError_t e = mmt::launch_colsum_reduce((const float*)ws, nblocks, ksets, d->H, o0, o1, o2, d->accumulate, (hipStream_t)stream);
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_colsum_reduce: %s", hipGetErrorString(e));
+}
+
+int mmt_grad_clip_scale(int32_t n_slabs, const float* const* slabs, const int64_t* sizes, float max_norm,
+                        float pending_scale, float* scale_out, float* norm_out, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (n_slabs < 1 || n_slabs > mmt::kMaxNormSlabs || !slabs || !sizes || !scale_out)
+    return lfail(MMT_E_INVALID, "mmt_grad_clip_scale: needs 1..%d slabs and an output", mmt::kMaxNormSlabs);
+  if (!workspace || workspace_bytes < (size_t)mmt::kNormBlocks * sizeof(float))
+    return lfail(MMT_E_WORKSPACE, "mmt_grad_clip_scale: workspace of %zu bytes needed", (size_t)mmt::kNormBlocks * sizeof(float));
+  mmt::NormSlabs a;
+  a.n = n_slabs;
+  for (int i = 0; i < n_slabs; ++i) {
+    if (!slabs[i] || sizes[i] <= 0 || (sizes[i] & 3) || ((uintptr_t)slabs[i] & 15))
+      return lfail(MMT_E_INVALID, "mmt_grad_clip_scale: slabs must be 16-byte aligned with a multiple of 4 elements");
+    a.ptr[i] = slabs[i]; a.n4[i] = sizes[i] >> 2;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mmt::sumsq_partial_kernel, dim3(mmt::kNormBlocks), dim3(256), 0, st, a, (float*)workspace);
+  hipLaunchKernelGGL(mmt::clip_scale_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, max_norm, pending_scale, scale_out, norm_out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_grad_clip_scale: %s", hipGetErrorString(e));
 }
 
 int mmt_accumulate_grad(float* acc, const void* g, int32_t g_dtype, int64_t n, void* stream) {

@@ -23,7 +23,7 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
            'mmt_attn_bwd', 'mmt_side_inputs',
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
-           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_colsum_reduce', 'mmt_accumulate_grad', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
+           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_colsum_reduce', 'mmt_accumulate_grad', 'mmt_grad_clip_scale', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
            'mmt_wgrad_bias_accumulate', 'mmt_wgrad_grouped', 'mmt_wgrad_group_workspace_bytes', 'mmt_wgrad_workspace_bytes', 'mmt_wgrad_set_cu_budget', 'mmt_embed_fwd', 'mmt_embed_bwd',
            'mmt_embed_workspace_bytes', 'mmt_xent_fwd', 'mmt_xent_bwd', 'mmt_ffn_gelu_gemm', 'mmt_ffn_dgelu_gemm', 'mmt_ffn_set_cu_budget')
 
@@ -169,6 +169,9 @@ def lib() -> ctypes.CDLL:
   L.mmt_wgrad_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int64]
   L.mmt_adamw_step.restype = ctypes.c_int
   L.mmt_adamw_step.argtypes = [ctypes.POINTER(AdamwDesc)] + [vp] * 8
+  L.mmt_grad_clip_scale.restype = ctypes.c_int
+  L.mmt_grad_clip_scale.argtypes = [ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), ctypes.c_float,
+                                    ctypes.c_float, vp, vp, vp, ctypes.c_size_t, vp]
   L.mmt_accumulate_grad.restype = ctypes.c_int
   L.mmt_accumulate_grad.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
   if L.mmt_abi_version() != MMT_ABI_VERSION:

@@ -182,10 +182,25 @@ class GradientBucketReducer:
   def clip_by_global_norm(self, max_norm: float, apply: bool = True) -> torch.Tensor:
     """Returns the clip factor min(1, max_norm / ||g||) as a device scalar; with apply=False the
     gradients are left alone (a fused optimizer multiplies them while it reads them)."""
-    norms = torch._foreach_norm(self.buckets)                 # one pass, no temporaries
     ps = getattr(self, 'pending_scale', 1.0)                  # buckets hold ps^-1 x the true gradient
-    total = torch.linalg.vector_norm(torch.stack(norms)) * ps
-    scale = torch.clamp(max_norm / (total + 1e-6), max=1.0).float() * ps
+    if self.buckets[0].is_cuda and len(self.buckets) <= 16:
+      # one streaming HIP pass over the slabs + a fixed-order sum; the clip factor is written on the device
+      import ctypes
+      from . import _lib
+      dev = self.buckets[0].device
+      if getattr(self, '_clip_ws', None) is None:
+        self._clip_ws = torch.empty(2048 + 2, dtype=torch.float32, device=dev)
+        self._clip_ptrs = (ctypes.c_void_p * len(self.buckets))(*[b.data_ptr() for b in self.buckets])
+        self._clip_sizes = (ctypes.c_int64 * len(self.buckets))(*[b.numel() for b in self.buckets])
+      scale = self._clip_ws[2048:2049].view(())
+      with torch.cuda.device(dev):
+        _lib.check(_lib.lib().mmt_grad_clip_scale(
+            len(self.buckets), self._clip_ptrs, self._clip_sizes, float(max_norm), float(ps), scale.data_ptr(),
+            self._clip_ws[2049:].data_ptr(), self._clip_ws.data_ptr(), 2048 * 4, torch.cuda.current_stream(dev).cuda_stream))
+    else:
+      norms = torch._foreach_norm(self.buckets)               # one pass, no temporaries
+      total = torch.linalg.vector_norm(torch.stack(norms)) * ps
+      scale = torch.clamp(max_norm / (total + 1e-6), max=1.0).float() * ps
     if apply:
       torch._foreach_mul_(self.buckets, scale)
       self.pending_scale = 1.0

@@ -407,3 +407,31 @@ def test_grouped_weight_gradients_match_fp32_reference(blocks):
   assert L.mmt_wgrad_group_workspace_bytes(1, bad, K) == 0
   if blocks == 1:
     assert L.mmt_wgrad_grouped(n, probs, K, None, 0, None) == -3          # MMT_E_WORKSPACE
+
+
+@pytest.mark.parametrize('pending', [1.0, 0.25])
+def test_grad_clip_scale_matches_global_norm(pending):
+  """mmt_grad_clip_scale over several slabs: norm = pending * ||all slabs||, scale = min(1, max / (norm + 1e-6)) *
+  pending, against float64 torch; clipped and unclipped cases; bitwise repeatable."""
+  import ctypes
+  from mmt_amd import _lib
+  L = _lib.lib()
+  torch.manual_seed(3)
+  slabs = [torch.randn(n, device='cuda') * s for n, s in ((1024 * 37, 1.0), (1024 * 5, 3.0), (4096, 0.1))]
+  ptrs = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in slabs])
+  sizes = (ctypes.c_int64 * 3)(*[t.numel() for t in slabs])
+  ws = torch.empty(2048, device='cuda')
+  out = torch.zeros(2, device='cuda')
+  true = pending * float(torch.sqrt(sum((t.double() ** 2).sum() for t in slabs)))
+  for max_norm in (1.0, 1e6):
+    vals = []
+    for _ in range(2):
+      _lib.check(L.mmt_grad_clip_scale(3, ptrs, sizes, max_norm, pending, out[0:1].data_ptr(), out[1:2].data_ptr(),
+                                       ws.data_ptr(), ws.numel() * 4, torch.cuda.current_stream().cuda_stream))
+      torch.cuda.synchronize()
+      vals.append(out.clone())
+    assert torch.equal(vals[0], vals[1])
+    scale, norm = float(out[0]), float(out[1])
+    assert abs(norm - true) / true < 1e-5
+    assert abs(scale - min(1.0, max_norm / (true + 1e-6)) * pending) / pending < 1e-5
+  assert L.mmt_grad_clip_scale(3, ptrs, sizes, 1.0, 1.0, out.data_ptr(), None, None, 0, None) == -3
