@@ -410,9 +410,10 @@ _wg_pending = {}
 
 
 def _flush_wgrad(device) -> None:
-  items = _wg_pending.pop(device, None)
-  if not items:
+  entry = _wg_pending.pop(device, None)
+  if not entry or not entry[1]:
     return
+  items = entry[1]
   side = _side_stream(device)
   side.wait_stream(torch.cuda.current_stream(device))     # every queued dy / x is final on the main stream
   L = _lib.lib()
@@ -442,10 +443,17 @@ def wgrad_accumulate_side_(dw, dy, x, dbias=None) -> bool:
   the side stream; the others go out at once."""
   device = dw.device
   if _WG_GROUP > 1 and _wgrad_groupable(dw, dy, x, dbias):
-    q = _wg_pending.setdefault(device, [])
-    if q and q[0][1].shape[0] != dy.shape[0]:        # another K: cannot share the slices
+    gid = _graph_task_id()
+    entry = _wg_pending.get(device)
+    if entry is not None and entry[0] != gid:        # left behind by a backward pass that raised: not ours to launch
+      _wg_pending.pop(device)
+      entry = None
+    if entry is not None and entry[1] and entry[1][0][1].shape[0] != dy.shape[0]:   # another K: cannot share the slices
       _flush_wgrad(device)
-      q = _wg_pending.setdefault(device, [])
+      entry = None
+    if entry is None:
+      entry = _wg_pending[device] = (gid, [])
+    q = entry[1]
     q.append((dw, dy, x, dbias))
     _side_stream(device)
     _mark_side(device)
