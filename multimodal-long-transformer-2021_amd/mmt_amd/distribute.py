@@ -124,7 +124,7 @@ class GradientBucketReducer:
         # once the write is enqueued.  Depending on the torch version the parameter's AccumulateGrad
         # node still runs its post-accumulate hook for such an undefined gradient (it does on 2.10), so
         # `_on_grad_ready` counts every parameter at most once per backward.
-        p._mmt_grad_ready_hooks = (self._on_grad_ready,)
+        p._mmt_grad_ready_hooks = (self._on_grad_ready_from_kernel,)
 
   def zero_grad(self):
     if not self.buckets_are_zero:      # a fused optimizer step may already have cleared them
@@ -141,8 +141,16 @@ class GradientBucketReducer:
     bucket all-reduces; earlier ones just accumulate locally."""
     self.armed = bool(armed)
 
+  def _on_grad_ready_from_kernel(self, p):
+    """A kernel that wrote p.grad itself reports that the write is enqueued."""
+    p._mmt_grad_deferred = False
+    self._on_grad_ready(p)
+
   def _on_grad_ready(self, p):
-    if not self.armed or id(p) in self._ready:
+    # a parameter whose gradient product is still queued (fused.wgrad_accumulate_deferred_: launched together with
+    # its encoder block's other weight gradients) is NOT ready when autograd fires the post-accumulate hook for the
+    # None its backward returned -- only when the kernel-side notification arrives
+    if not self.armed or id(p) in self._ready or getattr(p, '_mmt_grad_deferred', False):
       return
     self._ready.add(id(p))
     gi = self._bucket_of[p]

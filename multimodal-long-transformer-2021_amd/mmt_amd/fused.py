@@ -409,6 +409,25 @@ _WG_GROUP = int(os.environ.get('MMT_WGRAD_GROUP', '4'))
 _wg_pending = {}
 
 
+def _launch_wgrad_group(items, device, stream) -> None:
+  """The queued products on `stream` (the current stream of the caller's `torch.cuda.stream` context)."""
+  L = _lib.lib()
+  if len(items) == 1:
+    dw, dy, x, dbias = items[0][:4]
+    if not wgrad_accumulate_(dw, dy, x, dbias):
+      raise RuntimeError('mmt_wgrad_accumulate refused a shape _wgrad_groupable admitted')
+    return
+  K = items[0][1].shape[0]
+  arr = (_lib.WgradProblem * len(items))()
+  for q, (dw, dy, x, dbias, *_) in zip(arr, items):
+    q.dw, q.ldw, q.dbias = dw.data_ptr(), dw.stride(0), (None if dbias is None else dbias.data_ptr())
+    q.dy, q.ldy, q.x, q.ldx = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
+    q.M, q.N = dy.shape[1], x.shape[1]
+  ws = _wgrad_ws(device, max(16, L.mmt_wgrad_group_workspace_bytes(len(items), arr, K)))
+  with torch.cuda.device(device):
+    _lib.check(L.mmt_wgrad_grouped(len(items), arr, K, ws.data_ptr(), ws.numel(), stream.cuda_stream))
+
+
 def _flush_wgrad(device) -> None:
   entry = _wg_pending.pop(device, None)
   if not entry or not entry[1]:
@@ -416,25 +435,63 @@ def _flush_wgrad(device) -> None:
   items = entry[1]
   side = _side_stream(device)
   side.wait_stream(torch.cuda.current_stream(device))     # every queued dy / x is final on the main stream
-  L = _lib.lib()
   with torch.cuda.stream(side):
-    if len(items) == 1:
-      dw, dy, x, dbias = items[0]
-      if not wgrad_accumulate_(dw, dy, x, dbias):
-        raise RuntimeError('mmt_wgrad_accumulate refused a shape _wgrad_groupable admitted')
-    else:
-      K = items[0][1].shape[0]
-      arr = (_lib.WgradProblem * len(items))()
-      for q, (dw, dy, x, dbias) in zip(arr, items):
-        q.dw, q.ldw, q.dbias = dw.data_ptr(), dw.stride(0), (None if dbias is None else dbias.data_ptr())
-        q.dy, q.ldy, q.x, q.ldx = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0)
-        q.M, q.N = dy.shape[1], x.shape[1]
-      ws = _wgrad_ws(device, max(16, L.mmt_wgrad_group_workspace_bytes(len(items), arr, K)))
-      with torch.cuda.device(device):
-        _lib.check(L.mmt_wgrad_grouped(len(items), arr, K, ws.data_ptr(), ws.numel(), side.cuda_stream))
+    _launch_wgrad_group(items, device, side)
   for _, dy, x, _ in items:
     dy.record_stream(side)
     x.record_stream(side)
+
+
+# The same grouping for parameters that carry gradient-ready hooks (a data-parallel reducer: no side stream by
+# default): the products are queued and launched together on the CURRENT stream, and only then are the
+# parameters reported ready -- the reducer ignores autograd's own post-accumulate notification for a parameter
+# while `_mmt_grad_deferred` is set, so a bucket's all-reduce can never be enqueued ahead of its last product.
+_wg_deferred = {}
+
+
+def _flush_wgrad_deferred(device) -> None:
+  entry = _wg_deferred.pop(device, None)
+  if not entry or not entry[1]:
+    return
+  items = entry[1]
+  _launch_wgrad_group(items, device, torch.cuda.current_stream(device))
+  for item in items:
+    for prm in item[4]:
+      for hook in getattr(prm, '_mmt_grad_ready_hooks', ()):
+        hook(prm)
+
+
+def _flush_all_deferred():
+  for device in list(_wg_deferred):
+    _flush_wgrad_deferred(device)
+
+
+def wgrad_accumulate_deferred_(dw, dy, x, dbias, notify) -> bool:
+  """Queues dw += dy^T x (dbias += column sums) for a grouped launch on the current stream; `notify` = the
+  parameters whose gradient-ready hooks run once the launch is enqueued.  False: not a shape the grouped kernel
+  takes (the caller launches and notifies at once)."""
+  device = dw.device
+  if _WG_GROUP <= 1 or not _wgrad_groupable(dw, dy, x, dbias):
+    return False
+  gid = _graph_task_id()
+  entry = _wg_deferred.get(device)
+  if entry is not None and entry[0] != gid:              # left behind by a backward pass that raised
+    for item in _wg_deferred.pop(device)[1]:
+      for prm in item[4]:
+        prm._mmt_grad_deferred = False
+    entry = None
+  if entry is not None and entry[1] and entry[1][0][1].shape[0] != dy.shape[0]:
+    _flush_wgrad_deferred(device)
+    entry = None
+  if entry is None:
+    entry = _wg_deferred[device] = (gid, [])
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_all_deferred)    # end of this backward pass
+  for prm in notify:
+    prm._mmt_grad_deferred = True
+  entry[1].append((dw, dy, x, dbias, tuple(notify)))
+  if len(entry[1]) >= _WG_GROUP:
+    _flush_wgrad_deferred(device)
+  return True
 
 
 def wgrad_accumulate_side_(dw, dy, x, dbias=None) -> bool:

@@ -111,7 +111,20 @@ def _accumulate_dense_grads(weight, bias, dy2, x2):
     if weight.grad is None:
       weight.grad = torch.zeros_like(weight, dtype=torch.float32)
     fuse_b = want_b and bias.grad is not None and bias.grad.dtype == torch.float32 and bias.grad.is_contiguous()
-    wgrad = fused.wgrad_accumulate_side_ if fused.side_stream_ok(weight, bias) else fused.wgrad_accumulate_
+    side = fused.side_stream_ok(weight, bias)
+    if (not side and weight.is_cuda and weight.grad.dtype == torch.float32
+        and fused.wgrad_accumulate_deferred_(weight.grad, dy2, x2, bias.grad if fuse_b else None,
+                                             (weight, bias) if fuse_b else (weight,))):
+      # queued with the block's other weight gradients; the parameters are reported ready at the launch
+      if want_b and not fuse_b:
+        db = dy2.sum(0, dtype=torch.float32)
+        if bias.grad is None:
+          bias.grad = db.to(bias.dtype)
+        else:
+          bias.grad.add_(db)
+        _notify(bias)
+      return
+    wgrad = fused.wgrad_accumulate_side_ if side else fused.wgrad_accumulate_
     if weight.grad.dtype == torch.float32 and wgrad(weight.grad, dy2, x2, bias.grad if fuse_b else None):
       b_done = fuse_b
     elif weight.grad.dtype == torch.float32:
