@@ -679,7 +679,7 @@ hipError_t launch_drel_reduce(const BwdParams& p, bool bf16, hipStream_t st) {
 }
 
 hipError_t launch_attn_bwd(const BwdParams& p, int mode, bool bf16, hipStream_t st) {
-  if (mode == kBand && bf16 && (p.pat.id_mode == 0 || p.perm_1d)) return launch_attn_bwd_band_bf16(p, st);
+  if (mode == kBand && bf16 && (p.pat.id_mode == 0 || p.perm_1d || p.lean2d)) return launch_attn_bwd_band_bf16(p, st);
   return bf16 ? launch_bwd_t<__bf16>(p, mode, st) : launch_bwd_t<float>(p, mode, st);
 }
 

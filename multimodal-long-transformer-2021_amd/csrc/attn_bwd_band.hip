@@ -30,7 +30,7 @@ __device__ __forceinline__ void tile_to_lds(unsigned char* lds, const bf16x8 (&v
 // range check), staged ONCE per workgroup as Rp/32 swizzled 32 x 128-byte tile images at the start of LDS.  The
 // table products (E . Q^T), the dQ += E^T . dRel^T product and the mixed-id table rebuilds of the dK/dV pass
 // read their fragments from it instead of waiting for L2 once per item / per mixed-id tile.
-template <int Rp>
+template <int Rp, int REL>
 __device__ __forceinline__ void stage_e_image(unsigned char* elds, const void* emb, int n, int N, int R, int m, int tid) {
   using T = __bf16;
   const T* Eb = reinterpret_cast<const T*>(emb) + (long)n * 64;
@@ -39,7 +39,7 @@ __device__ __forceinline__ void stage_e_image(unsigned char* elds, const void* e
 #pragma unroll
   for (int c0 = 0; c0 < Rp * 8; c0 += 256) {
     const int ci = c0 + tid, row = ci >> 3, ch = ci & 7, rt = row & 31;
-    const bf16x8 e = buf16(re, (unsigned)icol(m, row) * es1b + ch * 16, 0u);
+    const bf16x8 e = buf16(re, (unsigned)(REL == 2 ? row : icol(m, row)) * es1b + ch * 16, 0u);   // 2-D ids: columns in id order
     *reinterpret_cast<bf16x8*>(elds + (row >> 5) * 4096 + rt * 128 + ((((ch >> 2) ^ ((rt >> 1) & 1))) << 6) + (ch & 3) * 16) = e;
   }
 }
@@ -48,14 +48,23 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// LDS float += v (no return value).  The rows of the per-wave dRel table are lane-private, so the only accesses
+// that meet on one address are this lane's own, and LDS executes a wave's instructions in order.
+__device__ __forceinline__ void lds_add_f32(int addr, float v) {
+#ifdef MMT_ABL_NOADD
+  asm volatile("" : : "v"(addr), "v"(v) : "memory"); return;
+#endif
+  asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
 
 // =========================================================================================
 // dQ, delta, dRel (lane = query row).
 // =========================================================================================
-template <int Rp, bool HAS_REL>
+template <int Rp, int REL>         // REL: 0 none, 1 = 1-D ids (permuted table), 2 = 2-D ids (columns in id order, attn_lean.h)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const BwdParams p) {
   using T = __bf16;
   using L = LeanLds<Rp>;
+  constexpr bool HAS_REL = REL != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -71,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   float* dtab = reinterpret_cast<float*>(wl + L::kTab);
   unsigned char* xlds = wl + L::kTab + 32 * dstride * 4;
   unsigned char* vlds = xlds + L::kTile;
+  int* lut = reinterpret_cast<int*>(smem + kEImg + 4 * kWave);        // REL == 2: one per workgroup
 
   const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
   const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
@@ -95,7 +105,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   }
   const int b = bn / p.N, n = bn - b * p.N;
   if (HAS_REL) {           // every wave of the workgroup takes part (the plane, hence E, is the same for all four)
-    stage_e_image<Rp>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
+    stage_e_image<Rp, REL>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
+    if (REL == 2) build_lut2d<Rp>(lut, p.pat, p.R, threadIdx.x, 256);
     __syncthreads();
   }
   if (!live) return;
@@ -156,8 +167,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   for (int i = lane; i < 32 * dstride; i += 64) dtab[i] = 0.f;
   if (HAS_REL) {
     float* bias_ts = reinterpret_cast<float*>(xlds);
-    if (lane < Rp)
-      bias_ts[lane] = (p.bias && icol(m, lane) < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)icol(m, lane) * p.N + n] * p.tscale : 0.f;   // by column
+    if (lane < Rp) {
+      const int idc = REL == 2 ? lane : icol(m, lane);
+      bias_ts[lane] = (p.bias && idc < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)idc * p.N + n] * p.tscale : 0.f;   // by column
+    }
+    if (REL == 2) tab[r * kTStride(Rp) + kZeroCol(Rp)] = 0.f;
     wave_lds_sync();
 #pragma unroll
     for (int rb = 0; rb < Rp / 32; ++rb) {
@@ -172,11 +186,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
       }
     }
     wave_lds_sync();
-    relfn = tab[r * kTStride(Rp)];
-    relfp = tab[r * kTStride(Rp) + 2 * m];
-    if (!split_item && q_ok && h == 0) {   // reused by the dK/dV pass for its one-id tiles
-      p.relfar[row_id * 2] = relfn;
-      p.relfar[row_id * 2 + 1] = relfp;
+    if (REL == 1) {
+      relfn = tab[r * kTStride(Rp)];
+      relfp = tab[r * kTStride(Rp) + 2 * m];
+      if (!split_item && q_ok && h == 0) {   // reused by the dK/dV pass for its one-id tiles
+        p.relfar[row_id * 2] = relfn;
+        p.relfar[row_id * 2 + 1] = relfp;
+      }
     }
   }
   wave_lds_sync();
@@ -187,6 +203,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   float* dtrow = dtab + r * dstride;
   const int trow_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)(tab + r * kTStride(Rp));
   const uint32_t drop_base = drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q);
+  // REL == 2: this lane's query on the patch grid, LDS addresses of the look-up table and of the lane's dRel row
+  const int xq2 = (int)__umulhi((unsigned)q, p.pat.magicP), yq2 = q - xq2 * p.pat.P;
+  const int lut_addr = lds_addr(lut), dtrow_addr = lds_addr(dtrow);
+  const int lim2 = p.pat.r + 1, nlim2 = -lim2;
 
   for (int it = 0; it < n_it; ++it) {
     const int k0 = w.at(it) * 32;
@@ -213,12 +233,53 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     }
     const bool no_gkey = p.pat.ng == 0 || k0 + 31 < p.pat.g0 || k0 >= p.pat.g0 + p.pat.ng;
     const TileClass tc = classify_tile(q0, k0, p.S, valid_len, W, m, ignore_band, no_gkey);
-    const bool one_id = !HAS_REL || tc.far_neg || tc.far_pos;
+    const bool one_id = REL != 2 && (!HAS_REL || tc.far_neg || tc.far_pos);
     const float relc = HAS_REL ? (tc.far_neg ? relfn : relfp) : 0.f;
     const int dbase = k0 - q + 4 * h;
 
     float pr[16];
-    if (tc.plain && one_id) {                                   // class A
+    int col4[16];                                               // REL == 2: byte offset of each element's table column
+    if (REL == 2) {
+      if (q0 + 31 < p.pat.I && k0 + 31 < p.pat.I && p.pat.P >= 32) {     // image x image: look-up table
+        const Ids2dTile t2 = ids2d_tile<1>(p.pat, lut_addr, k0 + 4 * h, xq2, yq2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) col4[i] = ids2d_col4<1>(t2, (i & 3) + 8 * (i >> 2), nlim2, lim2);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) col4[i] = 4 * col2d<Rp>(p.pat, p.R, q, k0 + 4 * h + (i & 3) + 8 * (i >> 2));
+      }
+      float sc[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sc[i] = fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)(trow_addr + col4[i])) - lse2;
+      if (tc.plain) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(sc[i]);
+      } else if (tc.edge) {
+        const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          pr[i] = __builtin_amdgcn_exp2f(sc[i] + ((unsigned)(dbase + (i & 3) + 8 * (i >> 2) + W) <= W2 ? 0.f : p.mask_add));
+      } else if (tc.outside) {
+        const unsigned gb = (unsigned)(k0 + 4 * h - p.pat.g0), ng = (unsigned)p.pat.ng;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          pr[i] = __builtin_amdgcn_exp2f(sc[i] + (gb + (unsigned)((i & 3) + 8 * (i >> 2)) < ng ? 0.f : p.mask_add));
+      } else {
+        const int kb = k0 + 4 * h;
+        const bool qv = q < valid_len;
+        const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ci = (i & 3) + 8 * (i >> 2);
+          const int kk = kb + ci, d = dbase + ci;
+          const bool near = ignore_band | ((unsigned)(d + W) <= W2);
+          const bool gk = (unsigned)(kk - p.pat.g0) < (unsigned)p.pat.ng;
+          const bool seg = (kk < valid_len) == qv;
+          const bool keep = (int)seg & ((int)near | (int)gk);
+          pr[i] = (kk < p.S && q_ok) ? __builtin_amdgcn_exp2f(keep ? sc[i] : sc[i] + p.mask_add) : 0.f;
+        }
+      }
+    } else if (tc.plain && one_id) {                            // class A
       const float rc = relc - lse2;
 #pragma unroll
       for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(fmaf(c[i], p.sscale, rc));
@@ -279,7 +340,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
       for (int i = 0; i < 16; ++i) ds[i] = pr[i] * (dp[i] - delta);
     }
     // dRel (unscaled; rel_gscale applied at the flush / in the stores)
-    if (HAS_REL) {
+    if (REL == 2) {                 // many keys of a row share an id: accumulate in the lane's dRel row
+      // LDS float atomics retire about one lane every three cycles on this chip (a tile's 16 x 64 updates cost more
+      // than the rest of the tile), so equal neighbours are merged first: along a row the ids come in runs -- a
+      // direction id for every key left of the core window, the 2r + 1 core ids, another direction id to the
+      // right -- and a lane's 16 keys are four groups of four consecutive ones.  Only the last element of a run
+      // issues its (exec-masked) update: two or three lanes-worth of updates per lane and tile instead of 16.
+      float run = ds[0] * p.rel_gscale;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool last = i == 15 || col4[i] != col4[i + 1];
+        if (last) lds_add_f32(dtrow_addr + col4[i], run);
+        if (i < 15) run = fmaf(ds[i + 1], p.rel_gscale, last ? 0.f : run);
+      }
+    } else if (HAS_REL) {
       if (one_id) {
         float t = 0.f;
 #pragma unroll
@@ -301,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) { a0[i] *= p.gscale; a1[i] *= p.gscale; }
-  if (HAS_REL) {
+  if (REL == 1) {
     const float fn = half_sum(far_neg_acc) * p.rel_gscale;
     const float fp = half_sum(far_pos_acc) * p.rel_gscale;
     if (h == 0) {
@@ -322,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     float* pt = p.part_dtab + slot * (32 * Rp);
     for (int i = lane; i < 32 * Rp; i += 64) {
       const int rr = i / Rp, id = i - rr * Rp;
-      const int col = tcol(1, m, id);
+      const int col = REL == 2 ? id : tcol(1, m, id);
       pt[i] = col < dstride ? dtab[rr * dstride + col] : 0.f;
     }
     return;
@@ -366,11 +440,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   }
   tile_to_lds(xlds, kt, lane);
   wave_lds_sync();
-  constexpr int kParkBias = Rp == 32 ? 8192 : 2 * L::kTab;      // byte offset of the parked bias sums inside the wave's LDS
+  // byte offset of the parked bias sums inside the wave's LDS: the V tile (dead by now).  (They used to sit at the
+  // start of the Q tile for Rp = 64, where the first id block's sums overwrote row 0 of the tile the second block's
+  // contraction still reads.)
+  const int kParkBias = L::kTab + 32 * dstride * 4 + L::kTile;
 #pragma unroll
   for (int rb = 0; rb < Rp / 32; ++rb) {
     const int id = rb * 32 + r;
-    const int col = tcol(1, m, id);
+    const int col = REL == 2 ? id : tcol(1, m, id);
     f32x16 e0 = {0}, e1 = {0};
     float bsum = 0.f;
     float vals[16];
@@ -423,10 +500,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
 // =========================================================================================
 // dK, dV (lane = key, registers = query rows).
 // =========================================================================================
-template <int Rp, bool HAS_REL>
+template <int Rp, int REL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const BwdParams p) {
   using T = __bf16;
   using L = LeanLds<Rp>;
+  constexpr bool HAS_REL = REL != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -440,6 +518,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   float* bias_ts = reinterpret_cast<float*>(dolds + L::kTile);
   float* rowc = bias_ts + Rp;            // per row of the current q tile: [0,32) lse*log2e, [32,64) delta,
                                          // [64,96) rel(clipped, d<=-m) - lse2, [96,128) rel(clipped, d>=m) - lse2
+  int* lut = reinterpret_cast<int*>(smem + kEImg + 4 * L::kDkv);       // REL == 2: one per workgroup
 
   if (p.comb_in_next) {          // trailing blocks: the dQ combine of the global rows (one row per wave)
     const int per_bn0 = (p.n_chunks * p.n_gblk + 3) >> 2;
@@ -470,7 +549,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   }
   const int b = bn / p.N, n = bn - b * p.N;
   if (HAS_REL) {
-    stage_e_image<Rp>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
+    stage_e_image<Rp, REL>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
+    if (REL == 2) build_lut2d<Rp>(lut, p.pat, p.R, threadIdx.x, 256);
     __syncthreads();
   }
   if (!live) return;
@@ -516,10 +596,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
     }
   }
   if (HAS_REL) {
-    if (lane < Rp)
-      bias_ts[lane] = (p.bias && icol(m, lane) < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)icol(m, lane) * p.N + n] * p.tscale : 0.f;   // by column
+    if (lane < Rp) {
+      const int idc = REL == 2 ? lane : icol(m, lane);
+      bias_ts[lane] = (p.bias && idc < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)idc * p.N + n] * p.tscale : 0.f;   // by column
+    }
   }
   wave_lds_sync();
+  // REL == 2: this lane's key on the patch grid
+  const int xk2 = (int)__umulhi((unsigned)k, p.pat.magicP), yk2 = k - xk2 * p.pat.P;
+  const int lut_addr = lds_addr(lut);
+  const int lim2 = p.pat.r + 1, nlim2 = -lim2;
 
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
   const int tab_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)tab;
@@ -549,16 +635,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       const int qq = min(q0 + r, p.S - 1);
       const float l2 = lse_bn[qq] * kLog2e;
       rowc[lane] = h == 0 ? l2 : delta_bn[qq];
-      if (HAS_REL) rowc[64 + lane] = relfar_bn[2 * qq + h] - l2;
+      if (REL == 1) rowc[64 + lane] = relfar_bn[2 * qq + h] - l2;
     }
     const bool no_gq = p.pat.ng == 0 || q0 + 31 < p.pat.g0 || q0 >= p.pat.g0 + p.pat.ng;
     const TileClass tc = classify_tile(q0, k0, p.S, valid_len, W, m, ignore_band, no_gq);
-    const bool one_id = !HAS_REL || tc.far_neg || tc.far_pos;
+    const bool one_id = REL != 2 && (!HAS_REL || tc.far_neg || tc.far_pos);
     wave_lds_sync();
     Frag<T> qf;
     frag_from_tile(qf, qlds, lane);
     if (HAS_REL && !one_id) {           // mixed ids: T rows = this q tile, with -lse2[row] folded in
       const float nl = -rowc[r];
+      if (REL == 2) tab[r * kTStride(Rp) + kZeroCol(Rp)] = nl;
 #pragma unroll
       for (int rb = 0; rb < Rp / 32; ++rb) {
         Frag<T> ef;                     // E rows of the table columns, from the workgroup's LDS image
@@ -584,7 +671,52 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
     const float* relrow = rowc + (tc.far_neg ? 64 : 96);   // clipped rel - lse2, per row
 
     float pr[16];
-    if (tc.plain && one_id) {                             // class A
+    if (REL == 2) {
+      // table value (rel - lse2 of the row) of each element, then the mask by tile class
+      float sc[16];
+      const int rowbase = tab_addr + h4 * (kTStride(Rp) * 4);
+      if (q0 + 31 < p.pat.I && k0 + 31 < p.pat.I && p.pat.P >= 32) {     // image x image: look-up table
+        const Ids2dTile t2 = ids2d_tile<-1>(p.pat, lut_addr, q0 + h4, xk2, yk2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ci = (i & 3) + 8 * (i >> 2);
+          sc[i] = fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)(rowbase + ci * (kTStride(Rp) * 4) + ids2d_col4<-1>(t2, ci, nlim2, lim2)));
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ci = (i & 3) + 8 * (i >> 2);
+          sc[i] = fmaf(c[i], p.sscale, *(lds_cfp)(size_t)(unsigned)(rowbase + ci * (kTStride(Rp) * 4) + 4 * col2d<Rp>(p.pat, p.R, q0 + h4 + ci, k)));
+        }
+      }
+      if (tc.plain) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) pr[i] = __builtin_amdgcn_exp2f(sc[i]);
+      } else if (tc.edge) {
+        const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          pr[i] = __builtin_amdgcn_exp2f(sc[i] + ((unsigned)(dbase - ((i & 3) + 8 * (i >> 2)) + W) <= W2 ? 0.f : p.mask_add));
+      } else if (tc.outside) {
+        const unsigned gb = (unsigned)(q0 + h4 - p.pat.g0), ng = (unsigned)p.pat.ng;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          pr[i] = __builtin_amdgcn_exp2f(sc[i] + (gb + (unsigned)((i & 3) + 8 * (i >> 2)) < ng ? 0.f : p.mask_add));
+      } else {
+        const bool kv = k < valid_len;
+        const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ci = (i & 3) + 8 * (i >> 2);
+          const int qq = q0 + ci + h4, d = dbase - ci;
+          const bool near = ignore_band | ((unsigned)(d + W) <= W2);
+          const bool gq = (unsigned)(qq - p.pat.g0) < (unsigned)p.pat.ng;
+          const bool seg = kv == (qq < valid_len);
+          const bool keep = (int)seg & ((int)near | (int)gq);
+          pr[i] = (qq < p.S && k_ok) ? __builtin_amdgcn_exp2f(keep ? sc[i] : sc[i] + p.mask_add) : 0.f;
+        }
+      }
+    } else if (tc.plain && one_id) {                      // class A
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + h4;      // q row inside the tile
@@ -688,23 +820,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
 }
 
 // ------------------------------------ launcher --------------------------------------------
-template <int Rp, bool HAS_REL>
+template <int Rp, int REL>
 static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
+  constexpr bool HAS_REL = REL != 0;
   BwdParams p = p_in;
   p.comb_in_next = 0;
   p.red_per_plane = p.red_live = (p.S + 127) >> 7;        // one dE partial per 128-row workgroup
   const int per_bn = (p.n_chunks * p.n_gblk + 3) / 4;
   dim3 grid(p.n_band_blocks + per_bn * p.B * p.N);
   const int e_img = HAS_REL ? Rp * 128 : 0;     // the workgroup's E image
-  p.dstride = (Rp == 32 && 2 * p.pat.m + 1 <= 27) ? 28 : kTStride(Rp);     // 27 r: conflict-free diagonal stores
-  const int lds_a = 4 * (LeanLds<Rp>::kTab + 32 * p.dstride * 4 + 2 * LeanLds<Rp>::kTile) + e_img, lds_b = 4 * LeanLds<Rp>::kDkv + e_img;
+  p.dstride = (REL != 2 && Rp == 32 && 2 * p.pat.m + 1 <= 27) ? 28 : kTStride(Rp);     // 27 r: conflict-free diagonal stores
+  const int n2 = 2 * p.pat.r + 3, lut_bytes = REL == 2 ? 4 * ((n2 * n2 + 15) & ~15) : 0;   // (dx, dy) look-up table, one per workgroup
+  const int lds_a = 4 * (LeanLds<Rp>::kTab + 32 * p.dstride * 4 + 2 * LeanLds<Rp>::kTile) + e_img + lut_bytes, lds_b = 4 * LeanLds<Rp>::kDkv + e_img + lut_bytes;
   if (lds_a > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_band_bf16_kernel<Rp, HAS_REL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_band_bf16_kernel<Rp, REL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
   if (lds_b > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_band_bf16_kernel<Rp, HAS_REL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_band_bf16_kernel<Rp, REL>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
-  hipLaunchKernelGGL((attn_bwd_dq_band_bf16_kernel<Rp, HAS_REL>), grid, dim3(256), lds_a, st, p);
+  hipLaunchKernelGGL((attn_bwd_dq_band_bf16_kernel<Rp, REL>), grid, dim3(256), lds_a, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   // With a dE reduce to follow, the two combines of the global-token partials ride in the next launches
@@ -713,7 +847,7 @@ static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
   if (p.n_gblk > 0 && !ride && (e = launch_bwd_dq_combine(p, true, st)) != hipSuccess) return e;
   p.comb_in_next = ride ? 1 : 0;
   dim3 grid_kv(grid.x + (ride ? (p.pat.ng * p.B * p.N + 3) / 4 : 0));
-  hipLaunchKernelGGL((attn_bwd_dkv_band_bf16_kernel<Rp, HAS_REL>), grid_kv, dim3(256), lds_b, st, p);
+  hipLaunchKernelGGL((attn_bwd_dkv_band_bf16_kernel<Rp, REL>), grid_kv, dim3(256), lds_b, st, p);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   if (p.n_gblk > 0 && !ride && (e = launch_bwd_dkv_combine(p, true, st)) != hipSuccess) return e;
   if (p.R > 0) e = launch_drel_reduce(p, true, st);
@@ -721,9 +855,10 @@ static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
 }
 
 hipError_t launch_attn_bwd_band_bf16(const BwdParams& p, hipStream_t st) {
+  if (p.lean2d) return p.Rp == 32 ? launch_lean<32, 2>(p, st) : launch_lean<64, 2>(p, st);
   const bool has_rel = p.pat.id_mode == 1 && p.R > 0;
-  if (p.Rp == 32) return has_rel ? launch_lean<32, true>(p, st) : launch_lean<32, false>(p, st);
-  return has_rel ? launch_lean<64, true>(p, st) : launch_lean<64, false>(p, st);
+  if (p.Rp == 32) return has_rel ? launch_lean<32, 1>(p, st) : launch_lean<32, 0>(p, st);
+  return has_rel ? launch_lean<64, 1>(p, st) : launch_lean<64, 0>(p, st);
 }
 
 }  // namespace mmt

@@ -16,9 +16,10 @@
 
 namespace mmt {
 
-template <int Rp, bool HAS_REL>
-__global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdParams p) {
+template <int Rp, int REL>        // REL: 0 no relative term, 1 = 1-D ids (permuted table), 2 = 2-D ids (columns in id order)
+__global__ __launch_bounds__(256, (Rp == 64 && REL == 2) ? 2 : 3) void attn_fwd_band_bf16_kernel(const FwdParams p) {
   using T = __bf16;
+  constexpr bool HAS_REL = REL != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -28,6 +29,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
   float* tab = reinterpret_cast<float*>(wl);
   unsigned char* vlds = wl + WaveLds<T, Rp>::kTBytesAligned;
   unsigned char* klds = vlds + 4096;
+  int* lut = reinterpret_cast<int*>(smem + 4 * kWaveBytes) + wave * ((lut2d_entries(p.pat) + 15) & ~15);   // REL == 2: wave-private
 
   // ---- work item ------------------------------------------------------------------------
   const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
@@ -115,10 +117,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
 #pragma unroll
     for (int rb = 0; rb < Rp / 32; ++rb)
 #pragma unroll
-      for (int s = 0; s < 4; ++s) ef[rb].v[s] = buf16(re, (unsigned)icol(m, rb * 32 + r) * es1b + 64 * h + 16 * s, 0u);   // row r <- id of column rb*32 + r
+      for (int s = 0; s < 4; ++s) ef[rb].v[s] = buf16(re, (unsigned)(REL == 2 ? rb * 32 + r : icol(m, rb * 32 + r)) * es1b + 64 * h + 16 * s, 0u);   // row r <- id of column rb*32 + r
     float* bias_ts = reinterpret_cast<float*>(vlds);
-    if (lane < Rp)
-      bias_ts[lane] = (p.bias && icol(m, lane) < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)icol(m, lane) * p.N + n] * p.tscale : 0.f;   // by column
+    if (lane < Rp) {
+      const int idc = REL == 2 ? lane : icol(m, lane);
+      bias_ts[lane] = (p.bias && idc < p.R) ? (float)reinterpret_cast<const T*>(p.bias)[(long)idc * p.N + n] * p.tscale : 0.f;   // by column
+    }
+    if (REL == 2) {
+      build_lut2d<Rp>(lut, p.pat, p.R, lane, 64);
+      tab[r * kTStride(Rp) + kZeroCol(Rp)] = 0.f;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -133,8 +141,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    relfn = tab[r * kTStride(Rp)];
-    relfp = tab[r * kTStride(Rp) + 2 * m];
+    if (REL == 1) {
+      relfn = tab[r * kTStride(Rp)];
+      relfp = tab[r * kTStride(Rp) + 2 * m];
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -145,6 +155,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
   const int trow_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)(tab + r * kTStride(Rp));
   const bool qblk_valid = q0 + 31 < valid_len, qblk_pad = q0 >= valid_len, qblk_in = q0 + 31 < p.S;
   const uint32_t drop_base = drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q);
+  // REL == 2: this lane's query on the patch grid, and the LDS address of the look-up table
+  const int xq2 = (int)__umulhi((unsigned)q, p.pat.magicP), yq2 = q - xq2 * p.pat.P;
+  const int lut_addr = lds_addr(lut);
+  const int lim2 = p.pat.r + 1, nlim2 = -lim2;
 
   for (int it = 0; it < n_it; ++it) {
     const int k0 = tile_at(it) * 32;
@@ -177,13 +191,56 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
     const bool band_all = ignore_band || (dmin >= -W && dmax <= W);
     const bool plain = in_range && seg_all && band_all;
     const bool far_neg = dmax <= -m, far_pos = dmin >= m;
-    const bool one_id = !HAS_REL || far_neg || far_pos;
+    const bool one_id = REL != 2 && (!HAS_REL || far_neg || far_pos);
     const bool no_gkey = p.pat.ng == 0 || k0 + 31 < p.pat.g0 || k0 >= p.pat.g0 + p.pat.ng;
     const float relc = HAS_REL ? (far_neg ? relfn : relfp) : 0.f;
     const int dbase = k0 - q + 4 * h;
 
     float pr[16], s2[16];
-    if (plain && one_id) {                                     // ---- class A
+    if (REL == 2) {
+      // ---- 2-D ids: the relative term first (image x image tiles through the look-up table, anything else with
+      //      the general id function), then the mask by tile class
+      float rel[16];
+      if (q0 + 31 < p.pat.I && k0 + 31 < p.pat.I && p.pat.P >= 32) {
+        const Ids2dTile t2 = ids2d_tile<1>(p.pat, lut_addr, k0 + 4 * h, xq2, yq2);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          rel[i] = *(lds_cfp)(size_t)(unsigned)(trow_addr + ids2d_col4<1>(t2, (i & 3) + 8 * (i >> 2), nlim2, lim2));
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) rel[i] = trow[col2d<Rp>(p.pat, p.R, q, k0 + 4 * h + (i & 3) + 8 * (i >> 2))];
+      }
+      if (plain) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s2[i] = fmaf(c[i], p.sscale, rel[i]);
+      } else if (in_range && seg_all && no_gkey && !ignore_band) {          // band edge
+        const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          s2[i] = fmaf(c[i], p.sscale, rel[i]) + ((unsigned)(dbase + (i & 3) + 8 * (i >> 2) + W) <= W2 ? 0.f : p.mask_add);
+      } else if (in_range && seg_all && !ignore_band && (dmin > W || dmax < -W)) {   // only the tile's global keys
+        const unsigned gb = (unsigned)(k0 + 4 * h - p.pat.g0), ng = (unsigned)p.pat.ng;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          s2[i] = fmaf(c[i], p.sscale, rel[i]) + (gb + (unsigned)((i & 3) + 8 * (i >> 2)) < ng ? 0.f : p.mask_add);
+      } else {
+        const int kb = k0 + 4 * h;
+        const bool qv = q < valid_len;
+        const unsigned W2 = 2u * (unsigned)W;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int ci = (i & 3) + 8 * (i >> 2);
+          const int kk = kb + ci, d = dbase + ci;
+          const bool near = ignore_band | ((unsigned)(d + W) <= W2);
+          const bool gk = (unsigned)(kk - p.pat.g0) < (unsigned)p.pat.ng;
+          const bool seg = (kk < valid_len) == qv;
+          const bool keep = (int)seg & ((int)near | (int)gk);
+          float s = fmaf(c[i], p.sscale, rel[i]);
+          s = keep ? s : s + p.mask_add;
+          s2[i] = kk < p.S ? s : -INFINITY;
+        }
+      }
+    } else if (plain && one_id) {                              // ---- class A
 #pragma unroll
       for (int i = 0; i < 16; ++i) s2[i] = fmaf(c[i], p.sscale, relc);
     } else if (plain) {                                        // ---- class B (HAS_REL, mixed ids)
@@ -330,15 +387,27 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdPar
 hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st) {
   const int per_bn = (p.n_chunks * p.n_rowblk + 3) / 4;
   dim3 grid(p.n_band_blocks + per_bn * p.B * p.N);
-  const bool has_rel = p.pat.id_mode == 1 && p.R > 0;
+  const int rel = p.R > 0 ? p.pat.id_mode : 0;
+  if (rel == 2) {                    // 2-D ids: table width chosen by the host (lean_rp), one look-up table per wave
+    const int n2 = 2 * p.pat.r + 3, lut_bytes = 4 * 4 * ((n2 * n2 + 15) & ~15);
+    if (p.lean_rp == 32) {
+      hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, 2>), grid, dim3(256), 4 * (WaveLds<__bf16, 32>::kBytes + 4096) + lut_bytes, st, p);
+    } else {
+      const int lds = 4 * (WaveLds<__bf16, 64>::kBytes + 4096) + lut_bytes;
+      if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_band_bf16_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, 2>), grid, dim3(256), lds, st, p);
+    }
+    return hipGetLastError();
+  }
   if (p.R <= 32) {
     const int lds = 4 * (WaveLds<__bf16, 32>::kBytes + 4096);
-    if (has_rel) hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, true>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, false>), grid, dim3(256), lds, st, p);
+    if (rel) hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, 1>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, 0>), grid, dim3(256), lds, st, p);
   } else {
     const int lds = 4 * (WaveLds<__bf16, 64>::kBytes + 4096);
-    if (has_rel) hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, true>), grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, false>), grid, dim3(256), lds, st, p);
+    if (rel) hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, 1>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, 0>), grid, dim3(256), lds, st, p);
   }
   return hipGetLastError();
 }

@@ -31,6 +31,7 @@ struct FwdParams {
   int n_chunks, chunk_tiles, n_rowblk;
   int n_band_blocks;  // B*N*ceil(S/128): blocks before the global-row items
   int perm_1d;        // 1-D ids with R >= 2m+1: table columns permuted, fast path allowed
+  int lean_rp;        // lean 2-D path: table width (32 | 64) that holds every id that can contribute
 };
 
 hipError_t launch_attn_fwd(const FwdParams& p, int mode, bool bf16, hipStream_t st);
@@ -55,6 +56,7 @@ struct BwdParams {
   float rel_gscale;                   // d(rel)     = ds * rel_gscale    (= scale, or 1)
   PatternDev pat;
   int perm_1d;
+  int lean2d;                         // 2-D ids on the lean path (Rp already narrowed to the ids that can contribute)
   int skip_global;                    // band items leave global rows / keys to the split items
   uint32_t drop_thresh, seed_lo, seed_hi;
   float inv_keep;

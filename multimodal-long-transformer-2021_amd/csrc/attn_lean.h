@@ -20,6 +20,58 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 
 
+// ---- 2-D relative ids (feature_utils.py:114-184) in the lean kernels ------------------------------------------------
+// The table keeps its columns in id order (column = id); ids that cannot contribute (>= R under the one-hot
+// lookup, or >= Rp) read the zero column Rp + 1 of the padded row.  For a tile whose 32 x 32 pairs are all
+// image x image, the id is a function of (dx, dy) = patch-grid offset key - query; clamped to +-(r + 1) the
+// offsets index a (2r + 3)^2 look-up table of column BYTE offsets kept in LDS, so that an element costs seven
+// VALU instructions and two LDS reads instead of two integer divisions and the region logic of id_2d():
+// the lane owns one end of the pair (its grid position is fixed for the kernel), the 16 registers walk 28
+// consecutive positions of the other end, which cross a patch-row boundary at most once when P >= 32.
+constexpr int kZeroCol(int Rp) { return Rp + 1; }
+__device__ __forceinline__ int lut2d_entries(const PatternDev& pat) { const int n2 = 2 * pat.r + 3; return n2 * n2; }
+template <int Rp>
+__device__ __forceinline__ void build_lut2d(int* lut, const PatternDev& pat, int R, int t, int nthreads) {
+  const int n2 = 2 * pat.r + 3, lim = pat.r + 1;
+  for (int e = t; e < n2 * n2; e += nthreads) {
+    const int cx = e / n2, cy = e - cx * n2;
+    const int id = id_2d(cx - lim, cy - lim, pat.r);
+    lut[e] = 4 * ((id < Rp && id < R) ? id : kZeroCol(Rp));
+  }
+}
+template <int Rp>
+__device__ __forceinline__ int col2d(const PatternDev& pat, int R, int q, int k) {    // general (any pair) column
+  const int id = rel_id(pat, q, k);
+  return ((unsigned)id < (unsigned)Rp && id < R) ? id : kZeroCol(Rp);
+}
+struct Ids2dTile { int g0, g1, dy0, dy1, wth; };
+// SGN = +1: the registers walk keys vb + ci and the lane owns the query (xfix, yfix);  SGN = -1: the registers walk
+// query rows and the lane owns the key.  vb = first walked position of this half-wave.
+template <int SGN>
+__device__ __forceinline__ Ids2dTile ids2d_tile(const PatternDev& pat, int lut_addr, int vb, int xfix, int yfix) {
+  const int xvb = (int)__umulhi((unsigned)vb, pat.magicP), yvb = vb - xvb * pat.P;
+  const int n2 = 2 * pat.r + 3, lim = pat.r + 1;
+  const int dx0 = SGN > 0 ? xvb - xfix : xfix - xvb;
+  const int dx1 = dx0 + SGN;
+  Ids2dTile t;
+  t.g0 = lut_addr + 4 * ((min(max(dx0, -lim), lim) + lim) * n2 + lim);
+  t.g1 = lut_addr + 4 * ((min(max(dx1, -lim), lim) + lim) * n2 + lim);
+  t.dy0 = SGN > 0 ? yvb - yfix : yfix - yvb;
+  t.dy1 = t.dy0 - SGN * pat.P;
+  t.wth = pat.P - yvb;
+  return t;
+}
+template <int SGN>
+__device__ __forceinline__ int ids2d_col4(const Ids2dTile& t, int ci, int nlim, int lim) {   // column byte offset of element ci
+  const bool wrap = ci >= t.wth;
+  const int dy = (wrap ? t.dy1 : t.dy0) + SGN * ci;
+  const int a = (wrap ? t.g1 : t.g0) + 4 * med3i(dy, nlim, lim);
+  return *(__attribute__((address_space(3))) const int*)(size_t)(unsigned)a;
+}
+__device__ __forceinline__ int lds_addr(const void* p) {
+  return (int)(unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 // Tiles a 32-row block visits: [a0, a0+lenA) U [b0, b0+lenB) U [c0, c0+lenC), ascending.
 struct TileWalkLean {
   int a0 = 0, lenA = 0, b0 = 0, lenB = 0, c0 = 0, lenC = 0;

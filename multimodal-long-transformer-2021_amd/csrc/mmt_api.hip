@@ -105,6 +105,18 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
   return pl;
 }
 
+// 2-D ids on the lean (bf16, structured pattern) kernels: table width that holds every id that can contribute --
+// image ids < (2r+1)^2 + 8, text ids <= 2m, never more than R (ids >= R contribute 0 under the one-hot lookup,
+// SURVEY App. B q1; the two cross-modal part ids are >= P^2 + 8 + 2m + 1 > any table here).  0 = not eligible
+// (the general kernels of attn_fwd.hip / attn_bwd.hip take the call).
+int lean2d_width(const mmt::PatternDev& pat, int R, bool dense) {
+  if (dense || pat.id_mode != MMT_IDS_2D || R <= 0) return 0;
+  const int d = 2 * pat.r + 1, n2 = d + 2;
+  if (n2 * n2 > 256) return 0;                       // look-up table of the clamped (dx, dy) grid
+  const int need = std::min(R, std::max(d * d + 8, 2 * pat.m + 1));
+  return need <= 32 ? 32 : (need <= 64 ? 64 : 0);
+}
+
 void fill_common(mmt::FwdParams& p, const mmt_attn_desc* d) {
   std::memset(&p, 0, sizeof(p));
   p.B = d->B; p.S = d->S; p.N = d->N; p.R = d->R;
@@ -174,7 +186,8 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     p.part_o = reinterpret_cast<float*>(workspace);
     p.part_ml = p.part_o + (size_t)desc->B * desc->N * pl.n_rowblk * pl.n_chunks * (32 * 64);
   }
-  const bool lean = bf16 && (p.pat.id_mode == 0 || p.perm_1d);   // attn_fwd_band.hip
+  p.lean_rp = lean2d_width(p.pat, desc->R, dense);
+  const bool lean = bf16 && (p.pat.id_mode == 0 || p.perm_1d || p.lean_rp);   // attn_fwd_band.hip
   p.part_scale = (lean && p.drop_thresh) ? p.inv_keep : 1.f;
   e = lean ? mmt::launch_attn_fwd_band_bf16(p, st) : mmt::launch_attn_fwd(p, mmt::kBand, bf16, st);
   if (e != hipSuccess) return fail(MMT_E_LAUNCH, "band forward launch: %s", hipGetErrorString(e));
@@ -216,6 +229,12 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   if (desc->R == 0) { p.pat.id_mode = 0; p.rel_ids = nullptr; }
   p.perm_1d = (!dense && p.pat.id_mode == MMT_IDS_1D && desc->R >= 2 * p.pat.m + 1) ? 1 : 0;
   p.drop_thresh = f.drop_thresh; p.seed_lo = f.seed_lo; p.seed_hi = f.seed_hi; p.inv_keep = f.inv_keep;
+  if (desc->dtype == MMT_BF16) {
+    if (const int w2 = lean2d_width(p.pat, desc->R, dense)) {      // lean 2-D path: the kernels run at the narrowed table width
+      p.lean2d = 1;
+      p.Rp = w2;
+    }
+  }
   float* ws = reinterpret_cast<float*>(workspace);
   p.delta = ws + pl.off_delta; p.relfar = ws + pl.off_relfar; p.drel = ws + pl.off_drel; p.part_dq = ws + pl.off_pdq;
   p.part_dtab = ws + pl.off_pdtab; p.part_dkv = ws + pl.off_pdkv; p.part_red = ws + pl.off_red;
@@ -224,8 +243,13 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   if (pl.split_rows) {
     p.skip_global = 1; p.n_gblk = pl.n_rowblk; p.n_chunks = pl.n_chunks; p.chunk_tiles = kChunkTiles;
   }
-  hipError_t e = mmt::launch_attn_bwd(p, dense ? mmt::kDense : mmt::kBand, desc->dtype == MMT_BF16,
-                                      reinterpret_cast<hipStream_t>(stream));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (p.lean2d && p.R > p.Rp && !p.drel_accum) {
+    // ids in [Rp, R) cannot occur (lean2d_width): their gradient rows are zero, and the dE reduce covers ids < Rp only
+    (void)hipMemsetAsync(drel_emb + (size_t)p.Rp * p.N * 64, 0, (size_t)(p.R - p.Rp) * p.N * 64 * sizeof(float), st);
+    if (p.drel_bias) (void)hipMemsetAsync(p.drel_bias + (size_t)p.Rp * p.N, 0, (size_t)(p.R - p.Rp) * p.N * sizeof(float), st);
+  }
+  hipError_t e = mmt::launch_attn_bwd(p, dense ? mmt::kDense : mmt::kBand, desc->dtype == MMT_BF16, st);
   if (e != hipSuccess) return fail(MMT_E_LAUNCH, "backward launch: %s", hipGetErrorString(e));
   return MMT_OK;
 }

@@ -85,8 +85,14 @@ def test_dense_operator_backward(cfg, dtype):
     dict(B=2, S=300, N=2, R=32, radius=64, g0=250, ng=8, m=12, valid=[300, 211]),
     dict(B=1, S=256, N=1, R=32, radius=0, g0=3, ng=40, m=12),
     dict(B=1, S=200, N=2, R=49, radius=20, g0=150, ng=5, id_mode=2, m=12, P=10, r=2),
+    # 2-D ids with a patch row of >= 32 positions (look-up-table tiles of the lean kernels, bf16): table width 32
+    # (r = 1, the reference's *_2d*.yaml) and 64 (r = 2); ragged batch; R below the text id range
+    dict(B=2, S=1200, N=2, R=49, radius=64, g0=1100, ng=8, id_mode=2, m=12, P=33, r=1, valid=[1200, 1111]),
+    dict(B=1, S=1152, N=2, R=49, radius=40, g0=0, ng=8, id_mode=2, m=12, P=32, r=2),
+    dict(B=1, S=1500, N=1, R=25, radius=100, g0=1400, ng=40, id_mode=2, m=12, P=37, r=1),
     dict(B=1, S=96, N=1, R=0, radius=8, g0=0, ng=1),
     dict(B=1, S=512, N=2, R=32, radius=64, g0=400, ng=8, m=12),
+    dict(B=1, S=512, N=2, R=41, radius=64, g0=400, ng=8, m=20),            # 1-D ids, table width 64 on the lean path
     # BASELINE config 2 shape: S=1024 = 2 + 28^2 + 238 text, radius 64, 8 globals [786,794) (fp32 there)
     dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'id_mode')))

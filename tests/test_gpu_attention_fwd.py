@@ -86,7 +86,13 @@ def test_dense_operator(cfg, dtype):
     dict(B=2, S=300, N=2, R=32, radius=64, g0=250, ng=8, m=12, valid=[300, 211]),
     dict(B=1, S=256, N=1, R=32, radius=0, g0=3, ng=40, m=12),              # radius 0, 2 global row blocks
     dict(B=1, S=200, N=2, R=49, radius=20, g0=150, ng=5, id_mode=2, m=12, P=10, r=2),
+    # 2-D ids with a patch row of >= 32 positions: image x image tiles go through the (dx, dy) look-up table of
+    # the lean kernels (bf16); the reference's *_2d*.yaml use r = 1, m = 12, R = 49 (table width 32), r = 2 needs 64
+    dict(B=2, S=1200, N=2, R=49, radius=64, g0=1100, ng=8, id_mode=2, m=12, P=33, r=1, valid=[1200, 1111]),
+    dict(B=1, S=1152, N=2, R=49, radius=40, g0=0, ng=8, id_mode=2, m=12, P=32, r=2),
+    dict(B=1, S=1500, N=1, R=25, radius=100, g0=1400, ng=40, id_mode=2, m=12, P=37, r=1),   # R cuts the text ids
     dict(B=1, S=96, N=1, R=0, radius=8, g0=0, ng=1),
+    dict(B=1, S=512, N=2, R=41, radius=64, g0=400, ng=8, m=20),            # 1-D ids, table width 64 on the lean path
     dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),           # BASELINE config 2 shape (N cut)
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'id_mode')))
 def test_structured_pattern(cfg, dtype):

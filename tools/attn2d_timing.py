@@ -1,4 +1,5 @@
-"""Dev tool: attention forward / backward timing with 2-D relative ids at the config-3 shape (general kernels today)."""
+"""Dev tool: attention forward / backward timing with 2-D relative ids at the config-3 shape (lean kernels; r = 1 is
+the reference's *_2d*.yaml setting and runs at table width 32, r = 2 needs width 64), with and without dropout."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multimodal-long-transformer-2021_amd'))
@@ -17,9 +18,13 @@ def t(fn, n=20):
   e1.record(); torch.cuda.synchronize()
   return e0.elapsed_time(e1) / n * 1e3
 for name, pat in (('1-D ids', mmt_amd.AttentionPattern(local_radius=64, global_start=3971, n_global=8, id_mode=1, max_dist=12)),
-                  ('2-D ids', mmt_amd.AttentionPattern(local_radius=64, global_start=3971, n_global=8, id_mode=2, max_dist=12, patches_per_row=63, core_layers=2))):
+                  ('2-D ids r=1', mmt_amd.AttentionPattern(local_radius=64, global_start=3971, n_global=8, id_mode=2, max_dist=12, patches_per_row=63, core_layers=1)),
+                  ('2-D ids r=2', mmt_amd.AttentionPattern(local_radius=64, global_start=3971, n_global=8, id_mode=2, max_dist=12, patches_per_row=63, core_layers=2))):
   e, bb = (emb[:32].contiguous(), bias[:32].contiguous()) if name == '1-D ids' else (emb, bias)
   out, lse = mmt_amd.relative_attention_forward(q, k, v, e, bb, pattern=pat)
   dout = torch.randn_like(out)
-  print(name, 'fwd us', round(t(lambda: mmt_amd.relative_attention_forward(q, k, v, e, bb, pattern=pat)), 1),
-        'bwd us', round(t(lambda: mmt_amd.relative_attention_backward(dout, q, k, v, e, bb, out, lse, pattern=pat)), 1))
+  for dp in (0.0, 0.1):
+    kw = dict(pattern=pat, dropout_p=dp, dropout_seed=5)
+    out, lse = mmt_amd.relative_attention_forward(q, k, v, e, bb, **kw)
+    print(name, 'dropout', dp, 'fwd us', round(t(lambda: mmt_amd.relative_attention_forward(q, k, v, e, bb, **kw)), 1),
+          'bwd us', round(t(lambda: mmt_amd.relative_attention_backward(dout, q, k, v, e, bb, out, lse, **kw)), 1))
