@@ -198,6 +198,9 @@ def main():
   ap.add_argument('--allreduce-mb', type=float, default=None,
                   help='allreduce mode: gradient bytes per rank in MB (default: the model\'s 444 MB)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--ids2d', action='store_true',
+                  help="the same workload with the 2-D relative ids of the reference's *_2d*.yaml (one core layer, "
+                       'relative_vocab_size 49) instead of the 1-D ids of BASELINE config 3 -- a side measurement, not the headline')
   args = ap.parse_args()
   if args.gpus < 1:
     ap.error('--gpus must be >= 1')
@@ -248,6 +251,8 @@ def main():
     assert ranks_seen == world, (ranks_seen, world)
 
   cfg = config3()
+  if args.ids2d:
+    cfg.update(R=49, core=1, P=63)
   B, S, N, D, R = cfg['B'], cfg['S'], cfg['N'], cfg['D'], cfg['R']
   mode = args.mode
   if mode == 'auto':
@@ -261,7 +266,8 @@ def main():
   else:
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     pat = mmt_amd.AttentionPattern(local_radius=cfg['radius'], global_start=cfg['g0'],
-                                   n_global=cfg['ng'], id_mode=1, max_dist=cfg['m'])
+                                   n_global=cfg['ng'], id_mode=2 if args.ids2d else 1, max_dist=cfg['m'],
+                                   patches_per_row=cfg.get('P', 0) if args.ids2d else 0, core_layers=cfg.get('core', 0))
     q, k, v = (torch.randn(B, S, N, D, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
     emb = (torch.randn(R, N, D, device=dev, generator=g) * 0.02).to(torch.bfloat16)
     bias = (torch.randn(R, N, device=dev, generator=g) * 0.02).to(torch.bfloat16)
@@ -372,7 +378,8 @@ def main():
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
         'config': {'workload': 'BASELINE config 3: BERT-base dims, S=4096 (2+63^2 patches+125 text), '
-                               'radius 64 + 8 global tokens, bf16, per-GPU batch 4',
+                               'radius 64 + 8 global tokens, bf16, per-GPU batch 4'
+                               + (' -- SIDE MEASUREMENT with the 2-D relative ids of *_2d*.yaml (1 core layer, R=49)' if args.ids2d else ''),
                    'step': mode, 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': S,
                    'parallelism': f'dp{world}', 'backend': backend if world > 1 else None,
                    'ranks_seen': ranks_seen, **step_info},

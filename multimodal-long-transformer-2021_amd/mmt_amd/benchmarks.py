@@ -23,6 +23,7 @@ def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.
       'task': {
           'micro_batch_size': cfg['B'],
           'model': {'encoder': {'mmt': {'relative_pos_max_distance': cfg['m'],
+                                       'relative_att_num_core_layers': cfg.get('core', 0),
                                        'relative_vocab_size': cfg['R']}},
                     'cls_heads': [{'inner_dim': 768, 'num_classes': 2, 'name': 'itm'}]},
           # mlm_max_selections_per_seq / mpp_max_selections_per_seq stay at the reference defaults
@@ -31,6 +32,7 @@ def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.
                          'global_batch_size': cfg['B'] * world, 'tasks': 'mlm,itm',
                          'mpp_fraction_to_mask': 0.0,
                          'relative_pos_max_distance': cfg['m'], 'local_radius': cfg['radius'],
+                         'relative_att_num_core_layers': cfg.get('core', 0),     # > 0: 2-D ids (*_2d*.yaml)
                          'num_global_tokens': cfg['ng']},
       }})
   strategy = distribute.DataParallelStrategy(torch.distributed.get_backend() if world > 1 else None)
