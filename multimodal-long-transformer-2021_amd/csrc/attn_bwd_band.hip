@@ -104,12 +104,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     live = q0 < p.S;
   }
   const int b = bn / p.N, n = bn - b * p.N;
-  if (HAS_REL) {           // every wave of the workgroup takes part (the plane, hence E, is the same for all four)
-    stage_e_image<Rp, REL>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
-    if (REL == 2) build_lut2d<Rp>(lut, p.pat, p.R, threadIdx.x, 256);
-    __syncthreads();
-  }
-  if (!live) return;
   const int q = q0 + r;
   const bool q_ok = q < p.S;
   const int valid_len = p.valid_len ? p.valid_len[b] : p.S;
@@ -133,13 +127,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
 
   TileWalkLean w;
   if (split_item) w.set_chunk(chunk * p.chunk_tiles, min(n_tiles, (chunk + 1) * p.chunk_tiles));
-  else w.set_band(p.pat, q0, p.S);
-  const int n_it = w.count();
+  else w.set_band(p.pat, live ? q0 : 0, p.S);
+  const int n_it = live ? w.count() : 0;
 
   Frag<T> qf, dof;
   bf16x8 kt[4], vt[4];
   float delta;
   {
+    // the item's own rows and its first K / V tile are requested BEFORE the workgroup stages the E image: the two
+    // memory round trips overlap instead of following each other (waves past the end read zeros and leave below)
     Frag<T> of;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -152,6 +148,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     for (int u = 0; u < 4; ++u) kt[u] = buf16(rk, voff_kc, (k0 + 8 * u) * ks1b);
 #pragma unroll
     for (int u = 0; u < 4; ++u) vt[u] = buf16(rv, voff_vc, (k0 + 8 * u) * vs1b);
+    if (HAS_REL) {           // every wave of the workgroup takes part (the plane, hence E, is the same for all four)
+      stage_e_image<Rp, REL>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
+      if (REL == 2) build_lut2d<Rp>(lut, p.pat, p.R, threadIdx.x, 256);
+      __syncthreads();
+    }
+    if (!live) return;
     float acc = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
@@ -548,12 +550,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
     live = k0 < p.S;
   }
   const int b = bn / p.N, n = bn - b * p.N;
-  if (HAS_REL) {
-    stage_e_image<Rp, REL>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
-    if (REL == 2) build_lut2d<Rp>(lut, p.pat, p.R, threadIdx.x, 256);
-    __syncthreads();
-  }
-  if (!live) return;
   const int k = k0 + r;
   const bool k_ok = k < p.S;
   const int valid_len = p.valid_len ? p.valid_len[b] : p.S;
@@ -577,8 +573,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
 
   TileWalkLean w;
   if (split_item) w.set_chunk(chunk * p.chunk_tiles, min(n_tiles, (chunk + 1) * p.chunk_tiles));
-  else w.set_band(p.pat, k0, p.S);
-  const int n_it = w.count();
+  else w.set_band(p.pat, live ? k0 : 0, p.S);
+  const int n_it = live ? w.count() : 0;
 
   Frag<T> kf, vf;
 #pragma unroll
@@ -595,6 +591,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       dot[u] = buf16(rdo, voff_oc, (q0 + 8 * u) * os1b);
     }
   }
+  if (HAS_REL) {           // E image after the item's loads are in flight (see the dQ kernel)
+    stage_e_image<Rp, REL>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
+    if (REL == 2) build_lut2d<Rp>(lut, p.pat, p.R, threadIdx.x, 256);
+    __syncthreads();
+  }
+  if (!live) return;
   if (HAS_REL) {
     if (lane < Rp) {
       const int idc = REL == 2 ? lane : icol(m, lane);
