@@ -222,6 +222,20 @@ int mmt_xent_fwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int
 int mmt_xent_bwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld,
                  const int32_t* labels, const float* lse, const float* coef, void* dlogits, int64_t ldd,
                  void* stream);
+/* The same with one more factor read on the device: dlogits *= gscale[0] (gscale may be NULL) -- the upstream
+ * gradient of a scalar loss, so that the host never reads it. */
+int mmt_xent_bwd_scaled(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld,
+                        const int32_t* labels, const float* lse, const float* coef, const float* gscale,
+                        void* dlogits, int64_t ldd, void* stream);
+/* The reduction of `weighted_sparse_categorical_crossentropy_loss`
+ * (src/modeling/losses/weighted_sparse_categorical_crossentropy_loss.py:36-43) and of the loss bookkeeping around it
+ * (src/tasks/pretraining.py:95-140: MLM / MPP weights masked by the example's ITM label) in one launch:
+ *   w_i = weight[i] * (mask ? mask[i / mask_div] : 1),   l_i = loss[i] * (lmul ? lmul[i] : 1)
+ *   num = sum_i w_i l_i,  den = sum_i w_i,  out3 = { divide_no_nan(num, den), num, den }
+ *   coef[i] = d out3[0] / d loss[i] = den != 0 ? w_i lmul_i / den : 0        (coef may be NULL)
+ * All arrays fp32 on the device; one workgroup, sums in a fixed order (bitwise reproducible). */
+int mmt_weighted_loss(int64_t rows, const float* loss, const float* weight, const float* lmul, const float* mask,
+                      int64_t mask_div, float* out3, float* coef, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Feed-forward GEMMs with the GELU in the epilogue (bf16 operands, fp32 accumulate; K11, csrc/ffn_gemm.hip).

@@ -64,25 +64,67 @@ __global__ __launch_bounds__(256) void xent_fwd_kernel(const T* logits, long ld,
   }
 }
 
-// dlogits[row][i] = (exp(logits - lse) - [i == label]) * coef[row]
+// dlogits[row][i] = (exp(logits - lse) - [i == label]) * coef[row] (* gscale[0])
 template <typename T>
 __global__ __launch_bounds__(256) void xent_bwd_kernel(const T* logits, long ld, int C, const int* labels,
-                                                       const float* lse, const float* coef, T* dlogits, long ldd) {
+                                                       const float* lse, const float* coef, const float* gscale,
+                                                       T* dlogits, long ldd) {
   const long row = blockIdx.y;
   const T* x = logits + row * ld;
   T* dx = dlogits + row * ldd;
   const int lab = labels[row];
   const bool has = (unsigned)lab < (unsigned)C;
-  const float l = lse[row], c = has ? coef[row] : 0.f;
+  const float l = lse[row], c = has ? coef[row] * (gscale ? gscale[0] : 1.f) : 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < C; i += gridDim.x * 256) {
     const float p = __expf(ldval(x, i) - l);
     dx[i] = (T)((p - (i == lab ? 1.f : 0.f)) * c);
   }
 }
 
+// Weighted mean of per-row losses with divide_no_nan, and its derivative per row -- one workgroup, fixed-order
+// sums (bitwise reproducible).  w_i = weight[i] * (mask ? mask[i / mask_div] : 1);  l_i = loss[i] * (lmul ? lmul[i] : 1)
+//   num = sum w_i l_i,  den = sum w_i,  out = {den != 0 ? num / den : 0, num, den},
+//   coef[i] = den != 0 ? w_i (lmul_i) / den : 0
+__global__ __launch_bounds__(256) void weighted_loss_kernel(long rows, const float* loss, const float* weight,
+                                                            const float* lmul, const float* mask, long mask_div,
+                                                            float* out3, float* coef) {
+  __shared__ float rn[256], rd[256];
+  const int t = threadIdx.x;
+  float num = 0.f, den = 0.f;
+  for (long i = t; i < rows; i += 256) {
+    const float w = weight[i] * (mask ? mask[i / mask_div] : 1.f);
+    num += w * loss[i] * (lmul ? lmul[i] : 1.f);
+    den += w;
+  }
+  rn[t] = num; rd[t] = den;
+  __syncthreads();
+#pragma unroll
+  for (int o = 128; o > 0; o >>= 1) {
+    if (t < o) { rn[t] += rn[t + o]; rd[t] += rd[t + o]; }
+    __syncthreads();
+  }
+  num = rn[0]; den = rd[0];
+  const float inv = den != 0.f ? 1.f / den : 0.f;
+  if (t == 0) { out3[0] = den != 0.f ? num / den : 0.f; out3[1] = num; out3[2] = den; }
+  if (coef)
+    for (long i = t; i < rows; i += 256)
+      coef[i] = weight[i] * (mask ? mask[i / mask_div] : 1.f) * (lmul ? lmul[i] : 1.f) * inv;
+}
+
 }  // namespace mmt
 
 extern "C" {
+
+int mmt_weighted_loss(int64_t rows, const float* loss, const float* weight, const float* lmul, const float* mask,
+                      int64_t mask_div, float* out3, float* coef, void* stream) {
+  if (!loss || !weight || !out3) return mmt::fail(MMT_E_INVALID, "mmt_weighted_loss: NULL argument");
+  if (rows <= 0 || (mask && mask_div <= 0)) return mmt::fail(MMT_E_INVALID, "mmt_weighted_loss: bad shape");
+  hipLaunchKernelGGL(mmt::weighted_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (long)rows, loss, weight, lmul, mask,
+                     (long)(mask ? mask_div : 1), out3, coef);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_weighted_loss: %s", hipGetErrorString(e));
+}
+
 
 int mmt_xent_fwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld, const int32_t* labels,
                  float* loss, float* lse, void* stream) {
@@ -98,6 +140,11 @@ int mmt_xent_fwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int
 
 int mmt_xent_bwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld, const int32_t* labels,
                  const float* lse, const float* coef, void* dlogits, int64_t ldd, void* stream) {
+  return mmt_xent_bwd_scaled(rows, C, dtype, logits, ld, labels, lse, coef, nullptr, dlogits, ldd, stream);
+}
+
+int mmt_xent_bwd_scaled(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld, const int32_t* labels,
+                        const float* lse, const float* coef, const float* gscale, void* dlogits, int64_t ldd, void* stream) {
   if (!logits || !labels || !lse || !coef || !dlogits) return mmt::fail(MMT_E_INVALID, "mmt_xent_bwd: NULL argument");
   if (rows <= 0 || rows > 65535 || C <= 0 || ld < C || ldd < C) return mmt::fail(MMT_E_INVALID, "mmt_xent_bwd: bad shape");
   if (dtype != MMT_F32 && dtype != MMT_BF16) return mmt::fail(MMT_E_INVALID, "mmt_xent_bwd: bad dtype %d", dtype);
@@ -105,8 +152,8 @@ int mmt_xent_bwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int
   int bx = (C + 256 * 8 - 1) / (256 * 8);
   bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
   dim3 grid(bx, (unsigned)rows);
-  if (dtype == MMT_BF16) hipLaunchKernelGGL(mmt::xent_bwd_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)logits, (long)ld, C, labels, lse, coef, (__bf16*)dlogits, (long)ldd);
-  else hipLaunchKernelGGL(mmt::xent_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, (long)ld, C, labels, lse, coef, (float*)dlogits, (long)ldd);
+  if (dtype == MMT_BF16) hipLaunchKernelGGL(mmt::xent_bwd_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)logits, (long)ld, C, labels, lse, coef, gscale, (__bf16*)dlogits, (long)ldd);
+  else hipLaunchKernelGGL(mmt::xent_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)logits, (long)ld, C, labels, lse, coef, gscale, (float*)dlogits, (long)ldd);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_xent_bwd: %s", hipGetErrorString(e));
 }

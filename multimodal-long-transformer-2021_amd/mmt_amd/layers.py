@@ -441,13 +441,27 @@ class RelativeTransformerLayers(nn.Module):
     return x
 
 
+_ROW_OFFSETS = {}
+
+
+def _row_offsets(B: int, S: int, device, plus: int = 0) -> torch.Tensor:
+  """Cached [B,1] int64 column b * S + plus: constants of the batch geometry, not rebuilt every step."""
+  key = (B, S, plus, str(device))
+  t = _ROW_OFFSETS.get(key)
+  if t is None:
+    t = _ROW_OFFSETS[key] = (torch.arange(B, device=device, dtype=torch.long) * S + plus).view(-1, 1)
+  return t
+
+
 def gather_rows_merged(sequence_tensor: torch.Tensor, position_sets):
   """One index_select for several heads: `position_sets` is a list of [B,M_i] position tensors
-  (gather_indexes semantics each); returns the list of [B*M_i, W] row blocks.  One gather forward
+  (gather_indexes semantics each) or plain ints (the same position in every example, e.g. a
+  classification head's [CLS] index); returns the list of [B*M_i, W] row blocks.  One gather forward
   and ONE dense scatter (zero-fill + index_add) backward instead of one per head."""
   B, S, W = sequence_tensor.shape
-  offs = (torch.arange(B, device=sequence_tensor.device) * S).view(-1, 1)
-  flat = [(p.long() + offs).reshape(-1) for p in position_sets]
+  dev = sequence_tensor.device
+  flat = [_row_offsets(B, S, dev, p).reshape(-1) if isinstance(p, int) else (p + _row_offsets(B, S, dev)).reshape(-1)
+          for p in position_sets]
   rows = sequence_tensor.reshape(B * S, W).index_select(0, torch.cat(flat))
   return list(torch.split(rows, [f.numel() for f in flat]))
 
@@ -458,6 +472,16 @@ def gather_indexes(sequence_tensor: torch.Tensor, positions: torch.Tensor) -> to
   flat_offsets = (torch.arange(B, device=positions.device) * S).view(-1, 1)
   flat_positions = (positions.long() + flat_offsets).reshape(-1)
   return sequence_tensor.reshape(B * S, W).index_select(0, flat_positions)
+
+
+def _head_layer_norm(ln: nn.LayerNorm, x: torch.Tensor) -> torch.Tensor:
+  """LayerNorm of a head: the HIP row kernel (fp32 gamma / beta read as they are, dgamma / dbeta added straight into
+  the fp32 master gradients) on the GPU, torch's elsewhere."""
+  H = x.shape[-1]
+  if (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and H % 8 == 0 and H <= 2048
+      and ln.weight.dtype == torch.float32 and ln.bias.dtype == torch.float32):
+    return fused.layer_norm(x, ln.weight, ln.bias, ln.eps)
+  return F.layer_norm(x, ln.normalized_shape, ln.weight.to(x.dtype), ln.bias.to(x.dtype), ln.eps)
 
 
 class MaskedLM(nn.Module):
@@ -488,8 +512,7 @@ class MaskedLM(nn.Module):
     x = _linear(x, self.dense_weight, self.dense_bias)
     if self.activation is not None:
       x = self.activation(x)
-    x = F.layer_norm(x, self.layer_norm.normalized_shape, self.layer_norm.weight.to(x.dtype),
-                     self.layer_norm.bias.to(x.dtype), self.layer_norm.eps)
+    x = _head_layer_norm(self.layer_norm, x)
     # the tied table also receives the embedding-lookup gradient through plain autograd, so it
     # must not use the accumulate-in-backward cast (one gradient-ready event per parameter)
     table = self.embedding_table
@@ -519,8 +542,7 @@ class MaskedPP(nn.Module):
 
   def forward(self, sequence_data, masked_positions, gathered=None):
     x = gather_indexes(sequence_data, masked_positions) if gathered is None else gathered
-    x = F.layer_norm(x, self.layer_norm.normalized_shape, self.layer_norm.weight.to(x.dtype),
-                     self.layer_norm.bias.to(x.dtype), self.layer_norm.eps)
+    x = _head_layer_norm(self.layer_norm, x)
     x = _linear(x, self.dense_weight, self.dense_bias)
     if self.activation is not None:
       x = self.activation(x)
@@ -570,22 +592,27 @@ class ClassificationHead(nn.Module):
 
 
 def weighted_sparse_categorical_crossentropy_loss(logits, labels, label_weights, metrics=None,
-                                                  name='', pos_weights=None):
+                                                  name='', pos_weights=None, example_mask=None):
   """`src/modeling/losses/weighted_sparse_categorical_crossentropy_loss.py:17-43` incl.
-  `divide_no_nan` (an all-zero weight vector gives loss 0, App. B q13)."""
+  `divide_no_nan` (an all-zero weight vector gives loss 0, App. B q13).  `example_mask` ([B], optional) multiplies
+  the weights of every row of its example (the ITM label that masks the MLM / MPP terms, `pretraining.py:101-109`)."""
   flat = logits.reshape(-1, logits.shape[-1])
-  if (flat.is_cuda and flat.dtype in (torch.float32, torch.bfloat16) and flat.stride(1) == 1
-      and 0 < flat.shape[0] <= 65535 and flat.shape[1] >= 64):
-    # wide rows (30522-way MLM, 512-way MPP): one HIP pass over the logits in their storage dtype
-    unweighted = fused.softmax_cross_entropy(flat, labels.reshape(-1)).view(labels.shape)
+  if flat.is_cuda and flat.dtype in (torch.float32, torch.bfloat16) and flat.stride(1) == 1 and 0 < flat.shape[0] <= 65535:
+    # per-row losses in one HIP pass over the logits in their storage dtype, then sums + guarded division +
+    # per-row derivative in one more launch
+    div = flat.shape[0] // example_mask.numel() if example_mask is not None else 1
+    loss = fused.weighted_softmax_cross_entropy(flat, labels.reshape(-1), label_weights, lmul=pos_weights,
+                                                mask=example_mask, mask_div=div)
   else:
     unweighted = F.cross_entropy(flat.float(), labels.reshape(-1).long(), reduction='none').view(labels.shape)
-  if pos_weights is not None:
-    unweighted = unweighted * pos_weights.to(unweighted.dtype)
-  w = label_weights.to(unweighted.dtype)
-  num, den = (w * unweighted).sum(), w.sum()
-  loss = torch.where(den != 0, num / torch.where(den != 0, den, torch.ones_like(den)),
-                     torch.zeros_like(num))
+    if pos_weights is not None:
+      unweighted = unweighted * pos_weights.to(unweighted.dtype)
+    w = label_weights.to(unweighted.dtype)
+    if example_mask is not None:
+      w = w * example_mask.to(w.dtype).reshape(-1, *([1] * (w.dim() - 1)))
+    num, den = (w * unweighted).sum(), w.sum()
+    loss = torch.where(den != 0, num / torch.where(den != 0, den, torch.ones_like(den)),
+                       torch.zeros_like(num))
   if metrics is not None:
     metrics.setdefault(f'{name}_loss', []).append(loss.detach())
   return loss

@@ -52,7 +52,7 @@ class MmtPretrainingModel(nn.Module):
     if mpp_positions is not None:
       sets.append(mpp_positions); names.append('/mpp')
     for head in self.classification_heads:
-      sets.append(torch.full((B, 1), head.cls_token_idx, dtype=torch.long, device=seq.device))
+      sets.append(int(head.cls_token_idx))
       names.append(head.name)
     rows = dict(zip(names, layers.gather_rows_merged(seq, sets))) if sets else {}
     if mlm_positions is not None:

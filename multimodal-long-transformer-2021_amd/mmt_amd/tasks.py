@@ -171,13 +171,12 @@ class PretrainingTask(_TaskBase):
   def build_losses(self, labels, model_outputs, metrics=None, aux_losses=None):
     """`pretraining.py:95-140`."""
     wsce = layers.weighted_sparse_categorical_crossentropy_loss
-    if 'itm_label_weights' in labels:    # mask MLM / MPP losses on negative pairs
-      itm = labels['itm_label_ids'].unsqueeze(1).float()
-      mlm_w, mpp_w = labels['mlm_label_weights'] * itm, labels['mpp_label_weights'] * itm
-    else:
-      mlm_w, mpp_w = labels['mlm_label_weights'], labels['mpp_label_weights']
-    total = wsce(model_outputs['mlm_logits'], labels['mlm_label_ids'], mlm_w, metrics, 'mlm')
-    total = total + wsce(model_outputs['mpp_logits'], labels['mpp_label_ids'], mpp_w, metrics, 'mpp')
+    # MLM / MPP losses are masked on negative pairs: the example's ITM label multiplies its rows' weights
+    itm = labels['itm_label_ids'].float() if 'itm_label_weights' in labels else None
+    total = wsce(model_outputs['mlm_logits'], labels['mlm_label_ids'], labels['mlm_label_weights'], metrics, 'mlm',
+                 example_mask=itm)
+    total = total + wsce(model_outputs['mpp_logits'], labels['mpp_label_ids'], labels['mpp_label_weights'], metrics,
+                         'mpp', example_mask=itm)
     if 'itm_label_weights' in labels:
       total = total + wsce(model_outputs['itm_logits'], labels['itm_label_ids'],
                            labels['itm_label_weights'], metrics, 'itm')

@@ -146,3 +146,17 @@ def softmax_xent(logits, labels):
   d[np.arange(x.shape[0]), lab] -= 1.0
   d[~ok] = 0.0
   return loss, d
+
+
+def weighted_loss(row_loss, weight, lmul=None, mask=None, mask_div=1):
+  """`weighted_sparse_categorical_crossentropy_loss.py:36-43` with the loss bookkeeping of `pretraining.py:101-109`
+  folded in: w_i = weight_i * mask[i // mask_div], l_i = row_loss_i * lmul_i; returns
+  (divide_no_nan(sum w l, sum w), d loss / d row_loss)."""
+  w = weight.astype(np.float64).reshape(-1)
+  if mask is not None:
+    w = w * np.repeat(mask.astype(np.float64).reshape(-1), mask_div)
+  lm = np.ones_like(w) if lmul is None else lmul.astype(np.float64).reshape(-1)
+  num, den = float((w * lm * row_loss.astype(np.float64)).sum()), float(w.sum())
+  if den == 0.0:
+    return 0.0, np.zeros_like(w)
+  return num / den, w * lm / den

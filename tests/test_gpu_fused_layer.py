@@ -248,6 +248,35 @@ def test_weighted_loss_uses_fused_xent_and_matches_torch():
   assert float(zero) == 0.0                                  # divide_no_nan
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('B,n,C,use_mask,use_lmul', [(4, 256, 30522, True, False), (4, 98, 512, True, True),
+                                                      (4, 1, 2, False, False), (3, 5, 7, False, True)])
+def test_weighted_loss_one_launch_matches_oracle(B, n, C, use_mask, use_lmul, dtype):
+  """mmt_xent_fwd + mmt_weighted_loss + mmt_xent_bwd_scaled (the whole loss term of pretraining.py:95-140: row
+  losses, weights masked by the example's ITM label, divide_no_nan, and the gradient under an upstream factor)
+  against the fp64 numpy restatement: loss 2e-5 relative, gradient 1e-6 (fp32) / one bf16 ulp."""
+  from mmt_amd import layers
+  rng = np.random.default_rng(B * 1000 + n + C)
+  logits = torch.from_numpy((rng.standard_normal((B, n, C)) * 3).astype(np.float32)).cuda().to(dtype).requires_grad_(True)
+  labels = rng.integers(0, C, size=(B, n))
+  w = (rng.random((B, n)) > 0.4).astype(np.float32) * rng.random((B, n)).astype(np.float32)
+  mask = (np.arange(B) % 2 == 0).astype(np.float32) if use_mask else None
+  lmul = (rng.random((B, n)) + 0.5).astype(np.float32) if use_lmul else None
+  dev = lambda x: None if x is None else torch.from_numpy(x).cuda()
+  loss = layers.weighted_sparse_categorical_crossentropy_loss(logits, dev(labels), dev(w), pos_weights=dev(lmul),
+                                                              example_mask=dev(mask))
+  (loss * 0.25).backward()                                  # an upstream factor, as loss / num_small_steps
+  rows, d_unit = lo.softmax_xent(logits.detach().float().cpu().numpy().reshape(B * n, C), labels.reshape(-1))
+  want, coef = lo.weighted_loss(rows, w, lmul, mask, n)
+  assert abs(float(loss) - want) <= 2e-5 * max(1.0, abs(want))
+  want_d = d_unit * (0.25 * coef)[:, None]
+  got_d = logits.grad.float().cpu().numpy().reshape(B * n, C)
+  tol = 1e-6 if dtype == torch.float32 else 2.0 ** -8 * max(1e-6, np.abs(want_d).max())
+  assert np.abs(got_d - want_d).max() <= tol + 1e-9
+  zero = layers.weighted_sparse_categorical_crossentropy_loss(logits, dev(labels), torch.zeros(B, n, device='cuda'))
+  assert float(zero) == 0.0                                  # divide_no_nan
+
+
 def test_wgrad_cu_budget_changes_the_split_not_the_result():
   """mmt_wgrad_set_cu_budget (data-parallel runs leave CUs to the collectives): same dW, other grid."""
   from mmt_amd import _lib, fused
