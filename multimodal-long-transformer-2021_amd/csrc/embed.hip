@@ -145,46 +145,83 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedParams p) {
       for (int i = 0; i < 8; ++i) { xw[j][i] = 0.f; acc[j][i] = 0.f; }
       if (id_ok && lane + 64 * j < nch) load_param(p.word_table + (long)id * p.H + (lane + 64 * j) * 8, xw[j]);
     }
-    long e = pos;
-    for (; e < lim; ++e) {
-      if (e != pos && p.sorted_ids[e] != id) break;
-      const int row = p.order[e];
-      const float mean = p.mean[row], rstd = p.rstd[row];
-      const int b = row / p.S, s = row - b * p.S, pj = s - p.patch_start;
-      const bool to_patch = p.dpatch != nullptr && (unsigned)pj < (unsigned)p.n_patch;
-      float t[NCH][8], xh[NCH][8];
-      float s1 = 0.f, s2 = 0.f;
+    // Rows with one id share the LayerNorm input (the id's table row), hence mean, rstd and x_hat: the LayerNorm
+    // gradient is linear in dout, so the piece needs only T = sum of its rows' (dropout-masked) dout and ONE
+    // evaluation of the LayerNorm backward -- no wave reductions and no dependent loads inside the row loop.
+    // Lane l looks at sorted position pos + l: piece length by ballot, row indices by readlane, four rows of dout
+    // in flight per step.
+    int n_rows, rowv = 0;
+    {
+      const long me = pos + (lane & 31);
+      const bool in_piece = me < lim && p.sorted_ids[me] == id;
+      if (me < lim) rowv = p.order[me];
+      const unsigned long long mism = ~__ballot(in_piece) & 0xFFFFFFFFull;      // first position that leaves the run
+      n_rows = mism ? __builtin_ctzll(mism) : 32;
+    }
+    const long e = pos + n_rows;
+    const int row0 = __builtin_amdgcn_readfirstlane(rowv);
+    const float mean = p.mean[row0], rstd = p.rstd[row0];
+    float tsum[NCH][8];
 #pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const int c = lane + 64 * j;
+    for (int j = 0; j < NCH; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { t[j][i] = 0.f; xh[j][i] = 0.f; }
-        if (c < nch) {
+      for (int i = 0; i < 8; ++i) tsum[j][i] = 0.f;
+    for (int k0 = 0; k0 < n_rows; k0 += 4) {
+      float t[4][NCH][8];
+      int rows4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = min(k0 + u, n_rows - 1);
+        rows4[u] = __builtin_amdgcn_readlane(rowv, k);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          const int c = lane + 64 * j;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) t[u][j][i] = 0.f;
+          if (c < nch && k0 + u < n_rows) Chunk<T>::load(reinterpret_cast<const T*>(p.dout) + (long)rows4[u] * p.H + c * 8, t[u][j]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + u >= n_rows) break;
+        const int row = rows4[u];
+        const int b = row / p.S, s = row - b * p.S, pj = s - p.patch_start;
+        const bool to_patch = p.dpatch != nullptr && (unsigned)pj < (unsigned)p.n_patch;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+          const int c = lane + 64 * j;
+          if (c >= nch) continue;
           const long off = (long)row * p.H + c * 8;
-          Chunk<T>::load(reinterpret_cast<const T*>(p.dout) + off, t[j]);
-          if (to_patch) {
-            float cp[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) cp[i] = t[j][i];
-            Chunk<T>::store(reinterpret_cast<T*>(p.dpatch) + ((long)b * p.n_patch + pj) * p.H + c * 8, cp);
-          }
+          if (to_patch) Chunk<T>::store(reinterpret_cast<T*>(p.dpatch) + ((long)b * p.n_patch + pj) * p.H + c * 8, t[u][j]);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
-            if (p.thresh16) t[j][i] = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? t[j][i] * p.inv_keep : 0.f;
-            xh[j][i] = (xw[j][i] - mean) * rstd;
-            const float dyh = t[j][i] * gam[j][i];
-            s1 += dyh;
-            s2 += dyh * xh[j][i];
-            acc_g[j][i] += t[j][i] * xh[j][i];
-            acc_bt[j][i] += t[j][i];
+            float v = t[u][j][i];
+            if (p.thresh16) v = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? v * p.inv_keep : 0.f;
+            tsum[j][i] += v;
           }
         }
       }
+    }
+    {
+      float xh[NCH][8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bool live = lane + 64 * j < nch;
+          xh[j][i] = live ? (xw[j][i] - mean) * rstd : 0.f;
+          const float dyh = tsum[j][i] * gam[j][i];
+          s1 += dyh;
+          s2 += dyh * xh[j][i];
+          acc_g[j][i] += tsum[j][i] * xh[j][i];
+          acc_bt[j][i] += tsum[j][i];
+        }
       const float c1 = wave_sum(s1) * invH, c2 = wave_sum(s2) * invH;
 #pragma unroll
       for (int j = 0; j < NCH; ++j)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[j][i] += rstd * (t[j][i] * gam[j][i] - c1 - xh[j][i] * c2);
+        for (int i = 0; i < 8; ++i) acc[j][i] = rstd * (tsum[j][i] * gam[j][i] - c1 - xh[j][i] * c2);
     }
     // whole run inside this piece -> add to the table row; else park the piece sum in the slab
     const bool run_ends = e >= p.rows || p.sorted_ids[e] != id;
