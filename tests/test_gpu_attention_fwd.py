@@ -93,6 +93,9 @@ def test_dense_operator(cfg, dtype):
     dict(B=1, S=1500, N=1, R=25, radius=100, g0=1400, ng=40, id_mode=2, m=12, P=37, r=1),   # R cuts the text ids
     dict(B=1, S=96, N=1, R=0, radius=8, g0=0, ng=1),
     dict(B=1, S=512, N=2, R=41, radius=64, g0=400, ng=8, m=20),            # 1-D ids, table width 64 on the lean path
+    dict(B=2, S=64, N=1, R=9, radius=8, g0=10, ng=2, valid=[0, 64]),      # an all-padding example next to a full one
+    dict(B=1, S=20, N=2, R=9, radius=4, g0=0, ng=1),                       # shorter than one 32-row tile
+    dict(B=1, S=96, N=1, R=1, radius=16, m=0),                             # a single relative id (m = 0)
     dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),           # BASELINE config 2 shape (N cut)
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'id_mode')))
 def test_structured_pattern(cfg, dtype):
