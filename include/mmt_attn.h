@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMT_ABI_VERSION 1
+#define MMT_ABI_VERSION 2
 
 enum {
   MMT_OK = 0,
@@ -58,7 +58,10 @@ enum {
  *   mask(q,k) = (q < valid_len[b]) == (k < valid_len[b])
  * otherwise (build-defined):
  *   mask(q,k) = segmented(q,k) && (|q-k| <= local_radius || global(q) || global(k)),
- *   global(x) = global_start <= x < global_start + n_global.                         */
+ *   global(x) = global_start <= x < global_start + n_global, or -- with global_index --
+ *   x is one of the n_global listed positions.  The structured kernels take the contiguous
+ *   form only; a listed set is served by materialising the mask (mmt_side_inputs with
+ *   materialize_pattern) and calling the dense operator with it.                       */
 typedef struct mmt_mask_desc {
   const int32_t* valid_len; /* [B] device ints (num_image_wordpieces + num_text_wordpieces),
                                NULL = every position valid                            */
@@ -69,6 +72,9 @@ typedef struct mmt_mask_desc {
   int32_t max_dist;         /* relative_pos_max_distance m (encoders.py:60)          */
   int32_t patches_per_row;  /* P  = image_size // patch_size        (MMT_IDS_2D)     */
   int32_t core_layers;      /* r  = relative_att_num_core_layers    (MMT_IDS_2D)     */
+  const int32_t* global_index; /* NULL: the contiguous range above; else n_global ascending,
+                               distinct positions in [0, S) on the device (global_start
+                               is ignored).  ABI 2.                                     */
 } mmt_mask_desc;
 
 /* One attention call: q,k,v,out are [B,S,N,D] views with element strides (D contiguous). */

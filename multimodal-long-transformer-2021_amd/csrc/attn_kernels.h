@@ -79,6 +79,7 @@ hipError_t launch_drel_reduce(const BwdParams& p, bool bf16, hipStream_t st);
 
 struct SideParams {
   PatternDev pat;
+  const int32_t* gidx;     // listed global positions (ascending, pat.ng of them) or NULL: the range [pat.g0, pat.g0 + pat.ng)
   int B, S;
   const int32_t *img_wp, *txt_wp;
   int materialize_pattern;

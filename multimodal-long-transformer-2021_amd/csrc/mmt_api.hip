@@ -57,7 +57,7 @@ int check_desc(const mmt_attn_desc* d) {
   if (!(d->dropout_p >= 0.f && d->dropout_p < 1.f)) return fail(MMT_E_INVALID, "dropout_p must be in [0,1)");
   const mmt_mask_desc& m = d->mask;
   if (m.local_radius < 0) return fail(MMT_E_INVALID, "local_radius must be >= 0");
-  if (m.n_global < 0 || m.global_start < 0 || m.global_start + m.n_global > d->S) return fail(MMT_E_INVALID, "global range outside the sequence");
+  if (m.n_global < 0 || (!m.global_index && (m.global_start < 0 || m.global_start + m.n_global > d->S))) return fail(MMT_E_INVALID, "global range outside the sequence");
   if (m.id_mode < MMT_IDS_NONE || m.id_mode > MMT_IDS_2D) return fail(MMT_E_INVALID, "bad id_mode");
   if (m.id_mode != MMT_IDS_NONE && m.max_dist < 0) return fail(MMT_E_INVALID, "max_dist must be >= 0");
   if (m.id_mode == MMT_IDS_2D) {
@@ -160,6 +160,8 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   if (!q || !k || !v || !out) return fail(MMT_E_INVALID, "q, k, v, out must not be NULL");
   if (desc->R > 0 && !rel_emb) return fail(MMT_E_INVALID, "R > 0 but rel_emb is NULL");
   const bool dense = att_mask != nullptr || rel_ids != nullptr;
+  if (!dense && desc->mask.global_index && desc->mask.n_global > 0)
+    return fail(MMT_E_UNSUPPORTED, "a listed global-token set has no structured kernel: materialise att_mask with mmt_side_inputs(materialize_pattern = 1) and pass it (dense operator)");
   const Plan pl = make_plan(desc, dense);
   if (pl.fwd_ws > 0 && (!workspace || workspace_bytes < pl.fwd_ws))
     return fail(MMT_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", pl.fwd_ws, workspace_bytes);
@@ -208,6 +210,8 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     return fail(MMT_E_INVALID, "q, k, v, out, dout, lse, dq, dk, dv must not be NULL");
   if (desc->R > 0 && (!rel_emb || !drel_emb)) return fail(MMT_E_INVALID, "R > 0 but rel_emb / drel_emb is NULL");
   const bool dense = att_mask != nullptr || rel_ids != nullptr;
+  if (!dense && desc->mask.global_index && desc->mask.n_global > 0)
+    return fail(MMT_E_UNSUPPORTED, "a listed global-token set has no structured kernel: materialise att_mask with mmt_side_inputs(materialize_pattern = 1) and pass it (dense operator)");
   const Plan pl = make_plan(desc, dense);
   if (!workspace || workspace_bytes < pl.bwd_ws)
     return fail(MMT_E_WORKSPACE, "workspace too small: need %zu bytes, got %zu", pl.bwd_ws, workspace_bytes);
@@ -269,14 +273,15 @@ int mmt_side_inputs(const mmt_mask_desc* mask, int32_t B, int32_t S,
   }
   if (mask->id_mode != MMT_IDS_NONE && mask->max_dist < 0) return fail(MMT_E_INVALID, "`text_relative_pos_max_distance` must be positive.");
   if (rel_ids_out && mask->id_mode == MMT_IDS_NONE) return fail(MMT_E_INVALID, "rel_ids_out requested with id_mode NONE");
-  if (materialize_pattern && (mask->local_radius < 0 || mask->n_global < 0 || mask->global_start < 0 ||
-                              mask->global_start + mask->n_global > S))
+  if (materialize_pattern && (mask->local_radius < 0 || mask->n_global < 0 ||
+                              (!mask->global_index && (mask->global_start < 0 || mask->global_start + mask->n_global > S))))
     return fail(MMT_E_INVALID, "bad pattern");
   mmt::SideParams p;
   p.pat = make_pattern(*mask, S);
   p.B = B; p.S = S;
   p.img_wp = num_image_wordpieces; p.txt_wp = num_text_wordpieces;
   p.materialize_pattern = materialize_pattern;
+  p.gidx = mask->n_global > 0 ? mask->global_index : nullptr;
   p.att_mask = att_mask_out; p.rel_ids = rel_ids_out; p.segment_ids = segment_ids_out;
   hipError_t e = mmt::launch_side_inputs(p, reinterpret_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(MMT_E_LAUNCH, "side inputs launch: %s", hipGetErrorString(e));

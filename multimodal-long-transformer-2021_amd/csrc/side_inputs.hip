@@ -6,6 +6,16 @@
 
 namespace mmt {
 
+// x is one of the n ascending positions of `list` (binary search; n is a few tens)
+__device__ __forceinline__ bool in_list(const int32_t* list, int n, int x) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (list[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  return lo < n && list[lo] == x;
+}
+
 __global__ __launch_bounds__(256) void side_inputs_kernel(const SideParams p) {
   const int S = p.S;
   const long row_chunks = (S + 3) >> 2;                 // int4 chunks per row
@@ -18,11 +28,15 @@ __global__ __launch_bounds__(256) void side_inputs_kernel(const SideParams p) {
     const int img = p.img_wp ? p.img_wp[b] : S, txt = p.txt_wp ? p.txt_wp[b] : 0;
     const int valid = img + txt;
     int mv[4], iv[4];
+    const bool gq = p.gidx && p.materialize_pattern && in_list(p.gidx, p.pat.ng, q);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = k0 + j;
       bool keep = (q < valid) == (k < valid);            // data_utils.py:321-322
-      if (p.materialize_pattern) keep = pattern_mask(p.pat, valid, q, k);
+      if (p.materialize_pattern) {
+        if (p.gidx) keep = keep && (abs(q - k) <= p.pat.radius || gq || in_list(p.gidx, p.pat.ng, k));   // listed global set
+        else keep = pattern_mask(p.pat, valid, q, k);
+      }
       mv[j] = keep ? 1 : 0;
       iv[j] = p.pat.id_mode ? rel_id(p.pat, q, k) : 0;
     }

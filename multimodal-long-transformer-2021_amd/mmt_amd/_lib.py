@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libmmt_attn.so')
 
-MMT_ABI_VERSION = 1
+MMT_ABI_VERSION = 2
 MMT_F32, MMT_BF16 = 0, 1
 MMT_IDS_NONE, MMT_IDS_1D, MMT_IDS_2D = 0, 1, 2
 MMT_FLAG_SCALE_BEFORE_ADD = 1
@@ -46,7 +46,8 @@ class MaskDesc(ctypes.Structure):
   _fields_ = [('valid_len', ctypes.c_void_p), ('local_radius', ctypes.c_int32),
               ('global_start', ctypes.c_int32), ('n_global', ctypes.c_int32),
               ('id_mode', ctypes.c_int32), ('max_dist', ctypes.c_int32),
-              ('patches_per_row', ctypes.c_int32), ('core_layers', ctypes.c_int32)]
+              ('patches_per_row', ctypes.c_int32), ('core_layers', ctypes.c_int32),
+              ('global_index', ctypes.c_void_p)]
 
 
 class AttnDesc(ctypes.Structure):

@@ -28,6 +28,11 @@ class AttentionPattern:
   (src/data/data_utils.py:321-322); id_mode 1 is the etcmodel 1-D generator
   (data_utils.py:300-301), id_mode 2 `MmtRelativePositionGenerator`
   (src/feature_utils.py:29).
+
+  Global tokens: the contiguous range [global_start, global_start + n_global), or `global_index`, any set of
+  positions (a tuple of ints).  A listed set that is in fact a contiguous run takes the structured kernels like
+  the range form; any other set is served through the dense operator with the materialised mask (correct, but
+  O(S^2) work and memory: there is no structured kernel for scattered global tokens).
   """
   local_radius: int = 1 << 30
   global_start: int = 0
@@ -36,15 +41,87 @@ class AttentionPattern:
   max_dist: int = 12
   patches_per_row: int = 0
   core_layers: int = 0
+  global_index: Optional[tuple] = None
 
-  def to_desc(self, valid_len: Optional[torch.Tensor] = None) -> _lib.MaskDesc:
+  def normalized(self) -> 'AttentionPattern':
+    """The same pattern with a listed global set sorted, de-duplicated and -- when it is a contiguous run -- turned
+    into the range form."""
+    if self.global_index is None:
+      return self
+    idx = tuple(sorted({int(i) for i in self.global_index}))
+    if any(i < 0 for i in idx):
+      raise ValueError('global_index must hold non-negative positions')
+    if not idx:
+      return dataclasses.replace(self, global_index=None, global_start=0, n_global=0)
+    if idx[-1] - idx[0] + 1 == len(idx):
+      return dataclasses.replace(self, global_index=None, global_start=idx[0], n_global=len(idx))
+    return dataclasses.replace(self, global_index=idx, global_start=0, n_global=len(idx))
+
+  def to_desc(self, valid_len: Optional[torch.Tensor] = None, device=None) -> _lib.MaskDesc:
     m = _lib.MaskDesc()
     m.valid_len = valid_len.data_ptr() if valid_len is not None else None
     m.local_radius = min(int(self.local_radius), (1 << 31) - 1)
     m.global_start, m.n_global = int(self.global_start), int(self.n_global)
     m.id_mode, m.max_dist = int(self.id_mode), int(self.max_dist)
     m.patches_per_row, m.core_layers = int(self.patches_per_row), int(self.core_layers)
+    m.global_index = None
+    if self.global_index is not None:
+      if device is None:
+        raise ValueError('a pattern with global_index needs the device its index list lives on')
+      m.n_global = len(self.global_index)
+      m.global_index = _index_list(self.global_index, device).data_ptr()
     return m
+
+
+_INDEX_LISTS = {}
+
+
+def _index_list(idx: tuple, device) -> torch.Tensor:
+  """Device copy of a listed global set (kept alive here: descriptors carry raw pointers)."""
+  key = (idx, str(device))
+  t = _INDEX_LISTS.get(key)
+  if t is None:
+    if len(_INDEX_LISTS) > 64:
+      _INDEX_LISTS.clear()
+    t = _INDEX_LISTS[key] = torch.tensor(idx, dtype=torch.int32, device=device)
+  return t
+
+
+_DENSE_CACHE = {}
+
+
+def _materialized(pattern: 'AttentionPattern', valid_len, B: int, S: int, device):
+  """(att_mask, relative_att_ids) int32 [B,S,S] of a pattern with a listed global set, through `mmt_side_inputs`;
+  the last result is kept, so that the layers of one encoder pass (same pattern, same valid_len tensor) share it."""
+  key = (pattern, B, S, str(device), None if valid_len is None else (valid_len.data_ptr(), valid_len._version))
+  hit = _DENSE_CACHE.get('last')
+  if hit is not None and hit[0] == key:
+    return hit[1], hit[2]
+  if any(i >= S for i in pattern.global_index):
+    raise ValueError('global_index position outside the sequence')
+  img = valid_len if valid_len is not None else torch.full((B,), S, dtype=torch.int32, device=device)
+  txt = torch.zeros(B, dtype=torch.int32, device=device)
+  mask = torch.empty((B, S, S), dtype=torch.int32, device=device)
+  ids = torch.empty((B, S, S), dtype=torch.int32, device=device) if pattern.id_mode != _lib.MMT_IDS_NONE else None
+  desc = pattern.to_desc(None, device)
+  with torch.cuda.device(device):
+    _lib.check(_lib.lib().mmt_side_inputs(desc, B, S, img.data_ptr(), txt.data_ptr(), 1, mask.data_ptr(),
+                                          None if ids is None else ids.data_ptr(), None, _stream_ptr(device)))
+  _DENSE_CACHE['last'] = (key, mask, ids)
+  return mask, ids
+
+
+def _resolve_pattern(pattern, att_mask, rel_ids, valid_len, q):
+  """Listed global sets: contiguous runs become the range form, anything else the dense operator's inputs."""
+  if pattern is None or pattern.global_index is None:
+    return pattern, att_mask, rel_ids
+  pattern = pattern.normalized()
+  if pattern.global_index is None:
+    return pattern, att_mask, rel_ids
+  if att_mask is not None or rel_ids is not None:
+    raise ValueError('pass either dense att_mask/relative_att_ids or a pattern, not both')
+  mask, ids = _materialized(pattern, valid_len, q.shape[0], q.shape[1], q.device)
+  return None, mask, ids
 
 
 def _stream_ptr(device) -> int:
@@ -78,7 +155,7 @@ def _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_bef
   d.flags = _lib.MMT_FLAG_SCALE_BEFORE_ADD if scale_before_add else 0
   d.dropout_p = float(dropout_p)
   d.dropout_seed = int(dropout_seed) & ((1 << 64) - 1)
-  d.mask = (pattern or AttentionPattern(id_mode=_lib.MMT_IDS_NONE)).to_desc(valid_len)
+  d.mask = (pattern or AttentionPattern(id_mode=_lib.MMT_IDS_NONE)).to_desc(valid_len, q.device)
   return d
 
 
@@ -115,6 +192,7 @@ def relative_attention_forward(q, k, v, rel_emb=None, rel_bias=None, *, att_mask
                                return_lse=True):
   """Forward only.  Returns (out [B,S,N,D] in q.dtype, lse fp32 [B,N,S])."""
   R = _check_inputs(q, k, v, rel_emb, rel_bias, att_mask, relative_att_ids, valid_len)
+  pattern, att_mask, relative_att_ids = _resolve_pattern(pattern, att_mask, relative_att_ids, valid_len, q)
   dense = att_mask is not None or relative_att_ids is not None
   if dense and pattern is not None:
     raise ValueError('pass either dense att_mask/relative_att_ids or a pattern, not both')
@@ -151,7 +229,8 @@ def side_inputs(pattern: AttentionPattern, num_image_wordpieces: torch.Tensor,
   mask = torch.empty((B, S, S), dtype=torch.int32, device=dev) if want_mask else None
   ids = torch.empty((B, S, S), dtype=torch.int32, device=dev) if want_ids else None
   seg = torch.empty((B, S), dtype=torch.int32, device=dev) if want_segment_ids else None
-  desc = pattern.to_desc(None)
+  pattern = pattern.normalized()
+  desc = pattern.to_desc(None, dev)
   ptr = lambda t: None if t is None else t.data_ptr()
   with torch.cuda.device(dev):
     _lib.check(_lib.lib().mmt_side_inputs(desc, B, S, ptr(img), ptr(txt), int(materialize_pattern),
@@ -172,6 +251,7 @@ def relative_attention_backward(dout, q, k, v, rel_emb, rel_bias, out, lse, *, a
   and contiguous: the table gradients are ADDED to these buffers (the fp32 master gradients) and
   returned as such."""
   R = _check_inputs(q, k, v, rel_emb, rel_bias, att_mask, relative_att_ids, valid_len)
+  pattern, att_mask, relative_att_ids = _resolve_pattern(pattern, att_mask, relative_att_ids, valid_len, q)
   B, S, N, D = q.shape
   dout = dout if dout.stride() == out.stride() else dout.contiguous()
   if out.stride() != dout.stride():

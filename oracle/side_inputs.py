@@ -186,13 +186,17 @@ def add_side_input_features(num_image_wordpieces: int, num_text_wordpieces: int,
 # function materialises it so the dense oracle can check the sparse kernels.
 # --------------------------------------------------------------------------
 def sparse_pattern_mask(seq_len: int, valid_len: int, local_radius: int,
-                        global_start: int = 0, n_global: int = 0) -> np.ndarray:
-  """mask(q,k) = segmented(q,k) & (|q-k| <= radius | global[q] | global[k])."""
+                        global_start: int = 0, n_global: int = 0, global_index=None) -> np.ndarray:
+  """mask(q,k) = segmented(q,k) & (|q-k| <= radius | global[q] | global[k]); the global tokens are the range
+  [global_start, global_start + n_global) or, when given, the listed positions `global_index`."""
   pos = np.arange(seq_len)
   ex = (pos < valid_len)
   seg = ex[:, None] == ex[None, :]
   band = np.abs(pos[:, None] - pos[None, :]) <= local_radius
-  is_g = (pos >= global_start) & (pos < global_start + n_global)
+  if global_index is not None:
+    is_g = np.isin(pos, np.asarray(list(global_index), dtype=np.int64))
+  else:
+    is_g = (pos >= global_start) & (pos < global_start + n_global)
   return (seg & (band | is_g[:, None] | is_g[None, :])).astype(np.int32)
 
 

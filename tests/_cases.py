@@ -14,10 +14,10 @@ def attention_inputs(B, S, N, R, seed=0, D=64, scale_q=1.0):
   return q, k, v, emb, bias
 
 
-def dense_side_inputs(B, S, valid, radius, g0, ng, id_mode, m, P=0, r=0):
+def dense_side_inputs(B, S, valid, radius, g0, ng, id_mode, m, P=0, r=0, gidx=None):
   """Materialised [B,S,S] mask + ids for a pattern (what the reference would be fed)."""
   valid = valid if valid is not None else [S] * B
-  mask = np.stack([si.sparse_pattern_mask(S, vl, radius, g0, ng) for vl in valid]).astype(np.int32)
+  mask = np.stack([si.sparse_pattern_mask(S, vl, radius, g0, ng, gidx) for vl in valid]).astype(np.int32)
   if id_mode:
     ids = si.relative_ids_from_desc(S, id_mode, m, P, r)
     ids = np.broadcast_to(ids, (B, S, S)).astype(np.int32).copy()

@@ -25,8 +25,8 @@ def test_header_symbols_are_exported(lib):
   L = lib.lib()
   for name in declared:
     assert hasattr(L, name), name
-  assert L.mmt_abi_version() == 1
-  assert int(re.search(r'#define MMT_ABI_VERSION (\d+)', header).group(1)) == 1
+  assert L.mmt_abi_version() == 2
+  assert int(re.search(r'#define MMT_ABI_VERSION (\d+)', header).group(1)) == 2
 
 
 def test_struct_layout_matches_header(lib):
@@ -43,7 +43,7 @@ def test_struct_layout_matches_header(lib):
     if m:
       flat += [x.strip().split('[')[0] for x in m.group(1).split(',')]
   assert flat == [f[0] for f in lib.AttnDesc._fields_]
-  assert ctypes.sizeof(lib.MaskDesc) == 8 + 7 * 4 + 4     # pointer + 7 ints, padded to 8
+  assert ctypes.sizeof(lib.MaskDesc) == 8 + 7 * 4 + 4 + 8     # pointer + 7 ints (padded to 8) + the ABI-2 index pointer
 
 
 def test_argument_errors_without_gpu(lib):

@@ -223,3 +223,52 @@ def test_2d_ids_long_sequence_forward_backward_against_oracle(dtype):
     got, want = t.grad.float().cpu().numpy(), ref[name]
     err = np.abs(got - want).max() / (max(1.0, np.abs(want).max()) if dtype == torch.bfloat16 else 1.0)
     assert err < tol_g, f'{name}: {err}'
+
+
+@pytest.mark.parametrize('dtype', DTYPES, ids=['f32', 'bf16'])
+def test_listed_global_tokens_forward_backward_and_materialised_mask(dtype):
+  """`mmt_mask_desc.global_index` (ABI 2): a scattered set of global tokens.  The materialised mask
+  (`mmt_side_inputs`, materialize_pattern) is bit-exact against the numpy restatement; output and every gradient,
+  through the dense operator fed that mask, match the dense oracle; a listed set that is a contiguous run gives
+  bit for bit what the range form gives (it takes the structured kernels); the structured entry points refuse a
+  listed set themselves."""
+  import mmt_amd
+  from mmt_amd import _lib
+  B, S, N, R, m = 2, 200, 2, 32, 12
+  gidx = (3, 4, 77, 150, 151, 199)
+  valid = [200, 161]
+  q, k, v, emb, bias = attention_inputs(B, S, N, R, seed=31)
+  dout = np.random.default_rng(32).standard_normal(q.shape).astype(np.float32)
+  if dtype == torch.bfloat16:
+    q, k, v, emb, bias, dout = (bf16_round(x) for x in (q, k, v, emb, bias, dout))
+  mask, ids = dense_side_inputs(B, S, valid, 16, 0, 0, 1, m, gidx=gidx)
+  pat = mmt_amd.AttentionPattern(local_radius=16, id_mode=1, max_dist=m, global_index=(151, 3, 150, 4, 199, 77, 77))
+  vl = torch.tensor(valid, dtype=torch.int32, device='cuda')
+  got = mmt_amd.side_inputs(pat, vl, torch.zeros_like(vl), S, materialize_pattern=True)
+  assert np.array_equal(got['att_mask'].cpu().numpy(), mask)
+  assert np.array_equal(got['relative_att_ids'].cpu().numpy(), ids)
+  ref_o, ref_lse = oa.relative_attention_fwd(q, k, v, emb, bias, mask, ids)
+  ref = oa.relative_attention_bwd(dout, q, k, v, emb, bias, mask, ids)
+  dev = lambda x: torch.from_numpy(x).cuda().to(dtype).contiguous()
+  tq, tk, tv, te, tb = (dev(x).requires_grad_(True) for x in (q, k, v, emb, bias))
+  out = mmt_amd.relative_attention(tq, tk, tv, te, tb, pattern=pat, valid_len=vl)
+  out.backward(dev(dout))
+  tol_o, tol_g = (2e-2, 3e-2) if dtype == torch.bfloat16 else (1e-3, 2e-3)
+  assert np.abs(out.detach().float().cpu().numpy() - ref_o).max() < tol_o
+  for name, t in (('dq', tq), ('dk', tk), ('dv', tv), ('drel_emb', te), ('drel_bias', tb)):
+    got_g, want = t.grad.float().cpu().numpy(), ref[name]
+    err = np.abs(got_g - want).max() / (max(1.0, np.abs(want).max()) if dtype == torch.bfloat16 else 1.0)
+    assert err < tol_g, f'{name}: {err}'
+  # a contiguous run, listed: the range form's kernels, bit for bit
+  run = mmt_amd.AttentionPattern(local_radius=16, id_mode=1, max_dist=m, global_index=(152, 150, 151, 153))
+  rng_ = mmt_amd.AttentionPattern(local_radius=16, id_mode=1, max_dist=m, global_start=150, n_global=4)
+  o1, l1 = mmt_amd.relative_attention_forward(tq.detach(), tk.detach(), tv.detach(), te.detach(), tb.detach(), pattern=run, valid_len=vl)
+  o2, l2 = mmt_amd.relative_attention_forward(tq.detach(), tk.detach(), tv.detach(), te.detach(), tb.detach(), pattern=rng_, valid_len=vl)
+  assert torch.equal(o1, o2) and torch.equal(l1, l2)
+  # the C entry point itself refuses a listed set without a dense mask
+  from mmt_amd import ops
+  d = ops._make_desc(tq.detach(), tk.detach(), tv.detach(), o1, R, pat.normalized(), vl, None, -10000.0, False, 0.0, 0)
+  ws = torch.empty(1 << 20, dtype=torch.uint8, device='cuda')
+  rc = _lib.lib().mmt_attn_fwd(d, tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), te.data_ptr(), tb.data_ptr(), None, None,
+                               o1.data_ptr(), None, ws.data_ptr(), ws.numel(), None)
+  assert rc == -2 and b'listed global-token set' in _lib.lib().mmt_last_error()      # MMT_E_UNSUPPORTED
