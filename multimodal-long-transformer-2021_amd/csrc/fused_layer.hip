@@ -204,15 +204,18 @@ __global__ __launch_bounds__(256, (W * NCH <= 12 ? 4 : 1)) void resid_ln_bwd_ker
   if (HAS_LN) { flush(acc_g); flush(acc_bt); }
 }
 
-// out[j][col] = sum_blocks part[block][j][col]   (fixed order).  Workgroup = 64 columns x 16
-// block groups; every thread sums nblocks/16 partials (unrolled), LDS combines the groups.
+// out[j][col] = sum_blocks part[block][j][col]   (fixed order).  Workgroup = 16 columns x 64 block groups: every
+// thread sums nblocks / 64 partials (independent loads), LDS combines the groups in group order.  (64 columns x 16
+// groups had 36 workgroups for the 3 x 768 sums of a residual block -- 36 of 256 CUs reading a 9.4 MB slab:
+// 12 us; 144 narrower workgroups take a third of that.)
+constexpr int kCsCols = 16, kCsGroups = 64;
 __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, int nblocks, int ksets, int H,
                                                              float* o0, float* o1, float* o2, int accumulate) {
-  __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int idx = blockIdx.x * 64 + lane;
+  __shared__ float red[kCsGroups][kCsCols];
+  const int c = threadIdx.x & (kCsCols - 1), grp = threadIdx.x / kCsCols;
+  const int idx = blockIdx.x * kCsCols + c;
   const int total = ksets * H;
-  const int per = (nblocks + 15) >> 4;
+  const int per = (nblocks + kCsGroups - 1) / kCsGroups;
   const int lo = grp * per, hi = min(nblocks, lo + per);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (idx < total) {
@@ -225,12 +228,12 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, 
     }
     for (; b < hi; ++b) a0 += part[(long)b * total + idx];
   }
-  red[grp][lane] = (a0 + a1) + (a2 + a3);
+  red[grp][c] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (grp == 0 && idx < total) {
     float s = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) s += red[g][lane];
+    for (int g = 0; g < kCsGroups; ++g) s += red[g][c];
     const int set = idx / H, col = idx - set * H;
     float* dst = set == 0 ? o0 : (set == 1 ? o1 : o2);
     dst[col] = accumulate ? dst[col] + s : s;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, 
 
 hipError_t launch_colsum_reduce(const float* part, int nblocks, int ksets, int H, float* o0, float* o1,
                                 float* o2, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ksets * H + 63) / 64), dim3(1024), 0, st, part, nblocks, ksets, H, o0, o1, o2, accumulate);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ksets * H + kCsCols - 1) / kCsCols), dim3(1024), 0, st, part, nblocks, ksets, H, o0, o1, o2, accumulate);
   return hipGetLastError();
 }
 
@@ -550,7 +553,7 @@ int mmt_ln_bwd(const mmt_rows_desc* d, const void* dy, const void* x, const floa
   hipError_t e = launch_bwd<false, true>(p, d->dtype == MMT_BF16, st, p.nblocks);
   if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_ln_bwd: %s", hipGetErrorString(e));
   if (d->defer_reduce) return MMT_OK;
-  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((2 * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, 2, d->H, dgamma, dbeta, (float*)nullptr, d->accumulate);
+  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((2 * d->H + mmt::kCsCols - 1) / mmt::kCsCols), dim3(1024), 0, st, p.part, p.nblocks, 2, d->H, dgamma, dbeta, (float*)nullptr, d->accumulate);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_ln_bwd reduce: %s", hipGetErrorString(e));
 }
@@ -588,7 +591,7 @@ int mmt_residual_block_bwd(const mmt_rows_desc* d, const void* dx_new_in, const 
   if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_residual_block_bwd: %s", hipGetErrorString(e));
   const int ksets = has_ln ? 3 : 1;
   if (d->defer_reduce) return MMT_OK;
-  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((ksets * d->H + 63) / 64), dim3(1024), 0, st, p.part, p.nblocks, ksets, d->H, dbias, dgamma, dbeta, d->accumulate);
+  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((ksets * d->H + mmt::kCsCols - 1) / mmt::kCsCols), dim3(1024), 0, st, p.part, p.nblocks, ksets, d->H, dbias, dgamma, dbeta, d->accumulate);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_residual_block_bwd reduce: %s", hipGetErrorString(e));
 }
@@ -689,7 +692,7 @@ int mmt_bias_gelu_bwd(const mmt_rows_desc* d, const void* dy, const void* u, con
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_bias_gelu_bwd: %s", hipGetErrorString(e));
   if (d->defer_reduce) return MMT_OK;
-  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((d->H + 63) / 64), dim3(1024), 0, st, p.part, (int)gy, 1, d->H, dbias, (float*)nullptr, (float*)nullptr, d->accumulate);
+  hipLaunchKernelGGL(mmt::colsum_reduce_kernel, dim3((d->H + mmt::kCsCols - 1) / mmt::kCsCols), dim3(1024), 0, st, p.part, (int)gy, 1, d->H, dbias, (float*)nullptr, (float*)nullptr, d->accumulate);
   e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_bias_gelu_bwd reduce: %s", hipGetErrorString(e));
 }

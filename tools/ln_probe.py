@@ -28,4 +28,4 @@ for p in (0.0, 0.1):
   bwd = lambda: _lib.check(L.mmt_residual_block_bwd(d, p_(dxn), p_(dh), p_(x_new), p_(gamma), p_(mean), p_(rstd), p_(d_o), p_(dx), p_(dbias), p_(dg), p_(db), p_(ws), ws.numel(), st))
   tf, tb = t(fwd), t(bwd)
   mb = rows * H * 2 / 1e6
-  print(f'{root[-6:]} p={p}: fwd {tf:.1f} us ({4 * mb / tf / 1e3:.2f} TB/s of 4 arrays)  bwd+reduce {tb:.1f} us ({5 * mb / tb / 1e3:.2f} TB/s of 5 arrays)')
+  print(f'{root[-6:]} p={p}: fwd {tf:.1f} us ({4 * mb / tf:.2f} TB/s over 4 arrays)  bwd+reduce {tb:.1f} us ({5 * mb / tb:.2f} TB/s over 5 arrays)')
