@@ -441,6 +441,39 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* dw, long ldw, 
   }
 }
 
+// The reduces of a grouped launch in ONE launch: workgroup ranges [blocks_end[j-1], blocks_end[j]) belong to problem j.
+struct ReduceGroup {
+  float* dw[8]; const float* slabs[8]; float* dbias[8]; const float* bias_part[8];
+  long ldw[8];
+  int M[8], N[8], blocks_end[8];
+  int n, split;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const ReduceGroup g) {
+  int j = 0;
+  while (j + 1 < g.n && (int)blockIdx.x >= g.blocks_end[j]) ++j;
+  const int b0 = j ? g.blocks_end[j - 1] : 0, nb = g.blocks_end[j] - b0, bid = blockIdx.x - b0;
+  const int M = g.M[j], N = g.N[j], split = g.split;
+  float* dw = g.dw[j]; const float* slabs = g.slabs[j]; const long ldw = g.ldw[j];
+  if (g.dbias[j]) {
+    for (int c = bid * 256 + threadIdx.x; c < M; c += nb * 256) {
+      float a = g.dbias[j][c];
+      for (int s2 = 0; s2 < split; ++s2) a += g.bias_part[j][(long)s2 * M + c];
+      g.dbias[j][c] = a;
+    }
+  }
+  const long n4 = (long)M * N / 4;
+  for (long c = (long)bid * 256 + threadIdx.x; c < n4; c += (long)nb * 256) {
+    const long e = c * 4;
+    const int m = (int)(e / N), n = (int)(e - (long)m * N);
+    f32x4 a = *reinterpret_cast<const f32x4*>(dw + (long)m * ldw + n);
+    for (int s2 = 0; s2 < split; ++s2) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(slabs + (long)s2 * M * N + e);
+      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    *reinterpret_cast<f32x4*>(dw + (long)m * ldw + n) = a;
+  }
+}
+
 }  // namespace mmt
 
 namespace {
@@ -596,12 +629,20 @@ extern "C" int mmt_wgrad_grouped(int32_t n, const mmt_wgrad_problem* problems, i
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmt::wgrad_dma_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL(mmt::wgrad_dma_group_kernel, dim3(tiles * split), dim3(512), lds, st, g);
   hipError_t e = hipGetLastError();
-  for (int i = 0; i < n && e == hipSuccess && split > 1; ++i) {
-    const mmt::WgradParams& p = g.p[i];
-    long blocks = ((long)p.M * p.N / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(mmt::wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.dw, (long)p.ldw, p.slabs, split, p.M, p.N,
-                       p.bias_part ? p.dbias : nullptr, p.bias_part);
+  if (e == hipSuccess && split > 1) {         // the slabs of every problem -> dw, one launch, slice order (as wgrad_reduce_kernel)
+    mmt::ReduceGroup r;
+    r.n = n; r.split = split;
+    int end = 0;
+    for (int i = 0; i < 8; ++i) {
+      const mmt::WgradParams& p = g.p[i < n ? i : n - 1];
+      long blocks = ((long)p.M * p.N / 4 + 255) / 256;
+      if (blocks > 1024) blocks = 1024;
+      if (i < n) end += (int)blocks;
+      r.dw[i] = p.dw; r.slabs[i] = p.slabs; r.ldw[i] = p.ldw; r.M[i] = p.M; r.N[i] = p.N;
+      r.dbias[i] = p.bias_part ? p.dbias : nullptr; r.bias_part[i] = p.bias_part;
+      r.blocks_end[i] = end;
+    }
+    hipLaunchKernelGGL(mmt::wgrad_reduce_group_kernel, dim3((unsigned)end), dim3(256), 0, st, r);
     e = hipGetLastError();
   }
   return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_wgrad_grouped: %s", hipGetErrorString(e));
