@@ -444,12 +444,13 @@ class RelativeTransformerLayers(nn.Module):
 _ROW_OFFSETS = {}
 
 
-def _row_offsets(B: int, S: int, device, plus: int = 0) -> torch.Tensor:
-  """Cached [B,1] int64 column b * S + plus: constants of the batch geometry, not rebuilt every step."""
-  key = (B, S, plus, str(device))
+def _row_offsets(B: int, S: int, device, plus: int = 0, dtype=torch.long) -> torch.Tensor:
+  """Cached [B,1] column b * S + plus: constants of the batch geometry, not rebuilt every step (kept in the
+  positions' own integer dtype: a mixed int32 + int64 add runs torch's slow casting kernel, 12 us for 1 K elements)."""
+  key = (B, S, plus, str(device), dtype)
   t = _ROW_OFFSETS.get(key)
   if t is None:
-    t = _ROW_OFFSETS[key] = (torch.arange(B, device=device, dtype=torch.long) * S + plus).view(-1, 1)
+    t = _ROW_OFFSETS[key] = (torch.arange(B, device=device, dtype=torch.long) * S + plus).to(dtype).view(-1, 1)
   return t
 
 
@@ -460,8 +461,11 @@ def gather_rows_merged(sequence_tensor: torch.Tensor, position_sets):
   and ONE dense scatter (zero-fill + index_add) backward instead of one per head."""
   B, S, W = sequence_tensor.shape
   dev = sequence_tensor.device
-  flat = [_row_offsets(B, S, dev, p).reshape(-1) if isinstance(p, int) else (p + _row_offsets(B, S, dev)).reshape(-1)
-          for p in position_sets]
+  tensors = [p for p in position_sets if not isinstance(p, int)]
+  idt = tensors[0].dtype if tensors and all(t.dtype == tensors[0].dtype for t in tensors) and \
+      tensors[0].dtype in (torch.int32, torch.int64) and B * S < 2 ** 31 else torch.long
+  flat = [_row_offsets(B, S, dev, p, idt).reshape(-1) if isinstance(p, int)
+          else (p.to(idt) + _row_offsets(B, S, dev, 0, idt)).reshape(-1) for p in position_sets]
   rows = sequence_tensor.reshape(B * S, W).index_select(0, torch.cat(flat))
   return list(torch.split(rows, [f.numel() for f in flat]))
 
