@@ -84,6 +84,13 @@ int mmt_bias_gelu_bwd(const mmt_rows_desc* desc, const void* dy, const void* u, 
 /* acc[i] += g[i] for i < n: fp32 master-gradient accumulation of a low-precision gradient
  * (the `AccumulateGrad` step behind `optimizer.apply_gradients`, src/tasks/pretraining.py:262-273).
  * g_dtype: MMT_F32 | MMT_BF16; acc must be 16-byte aligned, g 8-byte aligned. */
+/* out[c] (+)= sum_rows x[row, c] for a [rows, C] matrix (fp32 | bf16) with row stride ld >= C in elements and no
+ * alignment requirement beyond the element's: the bias gradient dy.sum(0) of a Dense layer (`tape.gradient`,
+ * src/tasks/pretraining.py:292-296) -- e.g. the output bias of the 30522-way MLM logits, whose rows start on odd
+ * 4-byte boundaries.  Fixed-order sums (16 row groups, then the groups in order). */
+size_t mmt_colsum_workspace_bytes(int64_t rows, int32_t C);
+int mmt_colsum(int64_t rows, int32_t C, int32_t dtype, const void* x, int64_t ld, float* out, int32_t accumulate,
+               void* workspace, size_t workspace_bytes, void* stream);
 int mmt_accumulate_grad(float* acc, const void* g, int32_t g_dtype, int64_t n, void* stream);
 
 /* Global-norm clip factor of the gradient slabs (`optimizer_config.gradient_clip_norm`, the reference's trainer

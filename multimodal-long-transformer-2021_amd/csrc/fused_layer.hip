@@ -240,6 +240,38 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, 
   }
 }
 
+// Column sums of a [rows, C] matrix with any row stride (the bias gradient of a Dense layer whose output has no
+// 16-byte row alignment, e.g. the 30522-way MLM logits): thread = two adjacent columns (4-byte bf16 / 8-byte fp32
+// loads), blockIdx.y = row group; eight rows in flight per thread; partials [row groups][C] -> colsum_reduce_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_pairs_kernel(const T* x, long ld, long rows, int C, float* part) {
+  const int c = (blockIdx.x * 256 + threadIdx.x) * 2;
+  if (c >= C) return;
+  const bool two = c + 1 < C;
+  float a0 = 0.f, a1 = 0.f;
+  const long r0 = blockIdx.y, step = gridDim.y;
+  auto load2 = [&](long row, float& u, float& v) {
+    const T* q = x + row * ld + c;
+    if (sizeof(T) == 2 && two && ((reinterpret_cast<uintptr_t>(q) & 3) == 0)) {
+      const uint32_t w = *reinterpret_cast<const uint32_t*>(q);
+      u = __uint_as_float(w << 16); v = __uint_as_float(w & 0xFFFF0000u);
+    } else {
+      u = (float)q[0]; v = two ? (float)q[1] : 0.f;
+    }
+  };
+  long row = r0;
+  for (; row + 7 * step < rows; row += 8 * step) {
+    float u[8], v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) load2(row + j * step, u[j], v[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a0 += u[j]; a1 += v[j]; }
+  }
+  for (; row < rows; row += step) { float u, v; load2(row, u, v); a0 += u; a1 += v; }
+  part[(long)blockIdx.y * C + c] = a0;
+  if (two) part[(long)blockIdx.y * C + c + 1] = a1;
+}
+
 hipError_t launch_colsum_reduce(const float* part, int nblocks, int ksets, int H, float* o0, float* o1,
                                 float* o2, int accumulate, hipStream_t st) {
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3((ksets * H + kCsCols - 1) / kCsCols), dim3(1024), 0, st, part, nblocks, ksets, H, o0, o1, o2, accumulate);
@@ -654,6 +686,28 @@ int mmt_adamw_step(const mmt_adamw_desc* d, float* param, float* grad, float* ex
                      exp_avg_sq, (__bf16*)param_bf16, chunk_wd, grad_scale, n_chunks, a);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_adamw_step: %s", hipGetErrorString(e));
+}
+
+size_t mmt_colsum_workspace_bytes(int64_t rows, int32_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  return (size_t)(rows < 16 ? rows : 16) * C * sizeof(float);
+}
+
+int mmt_colsum(int64_t rows, int32_t C, int32_t dtype, const void* x, int64_t ld, float* out, int32_t accumulate,
+               void* ws, size_t ws_bytes, void* stream) {
+  if (!x || !out) return lfail(MMT_E_INVALID, "mmt_colsum: NULL argument");
+  if (rows <= 0 || C <= 0 || ld < C) return lfail(MMT_E_INVALID, "mmt_colsum: bad shape");
+  if (dtype != MMT_F32 && dtype != MMT_BF16) return lfail(MMT_E_INVALID, "mmt_colsum: bad dtype %d", dtype);
+  if (!ws || ws_bytes < mmt_colsum_workspace_bytes(rows, C)) return lfail(MMT_E_WORKSPACE, "mmt_colsum: workspace too small");
+  const int gy = (int)(rows < 16 ? rows : 16);
+  dim3 grid(((C + 1) / 2 + 255) / 256, gy);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MMT_BF16) hipLaunchKernelGGL(mmt::colsum_pairs_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)x, (long)ld, (long)rows, C, (float*)ws);
+  else hipLaunchKernelGGL(mmt::colsum_pairs_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (long)ld, (long)rows, C, (float*)ws);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return lfail(MMT_E_LAUNCH, "mmt_colsum: %s", hipGetErrorString(e));
+  e = mmt::launch_colsum_reduce((const float*)ws, gy, 1, C, out, nullptr, nullptr, accumulate, st);
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_colsum reduce: %s", hipGetErrorString(e));
 }
 
 int mmt_bias_gelu_fwd(const mmt_rows_desc* d, const void* u, const float* bias, void* y, void* stream) {

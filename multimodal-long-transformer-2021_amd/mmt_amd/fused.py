@@ -291,6 +291,26 @@ def ffn_dgelu_gemm(dy: torch.Tensor, w: torch.Tensor, u: torch.Tensor, bias: Opt
                                              _p(bias) if bias is not None else None, _p(du), N, M, N, K, _stream(dy)))
   return du
 
+def colsum(x2: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+  """fp32 [C] column sums of a 2-D fp32 | bf16 tensor with unit column stride (any row stride / alignment): the bias
+  gradient `dy.sum(0)`.  With `out` (fp32, contiguous [C]) the sums are ADDED to it."""
+  if not (x2.is_cuda and x2.dim() == 2 and x2.stride(1) == 1 and x2.dtype in (torch.float32, torch.bfloat16)
+          and x2.shape[0] > 0 and x2.shape[1] > 0):
+    s = x2.sum(0, dtype=torch.float32)
+    return s if out is None else out.add_(s)
+  rows, C = x2.shape
+  L = _lib.lib()
+  ws = torch.empty(max(L.mmt_colsum_workspace_bytes(rows, C), 16), dtype=torch.uint8, device=x2.device)
+  acc = out is not None
+  if acc and (out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != C):
+    raise ValueError('colsum: out must be a contiguous fp32 [C] tensor')
+  res = out if acc else torch.empty(C, dtype=torch.float32, device=x2.device)
+  with torch.cuda.device(x2.device):
+    _lib.check(L.mmt_colsum(rows, C, _dtype_code(x2.dtype), _p(x2), x2.stride(0), _p(res), int(acc), _p(ws), ws.numel(),
+                            _stream(x2)))
+  return res
+
+
 def accumulate_grad_(acc: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
   """acc (fp32, contiguous) += g (fp32 | bf16), one streaming kernel."""
   if (not acc.is_cuda or acc.dtype != torch.float32 or not acc.is_contiguous() or not g.is_contiguous()

@@ -100,6 +100,19 @@ def _notify(param):
     hook(param)
 
 
+def _add_bias_grad(bias, dy2):
+  """bias.grad += dy2.sum(0): the HIP column-sum kernel, straight into an fp32 master gradient when there is one."""
+  g = bias.grad
+  if dy2.is_cuda and g is not None and g.dtype == torch.float32 and g.is_contiguous():
+    fused.colsum(dy2, out=g)
+    return
+  db = fused.colsum(dy2) if dy2.is_cuda else dy2.sum(0, dtype=torch.float32)
+  if g is None:
+    bias.grad = db.to(bias.dtype)
+  else:
+    g.add_(db)
+
+
 def _accumulate_dense_grads(weight, bias, dy2, x2):
   """weight.grad (fp32) += dy2^T @ x2 and bias.grad += dy2.sum(0) for a Dense layer y = x W^T + b, written
   straight into the master gradients: the hand-written split-K kernel (bias column sums fused, on the
@@ -117,11 +130,7 @@ def _accumulate_dense_grads(weight, bias, dy2, x2):
                                              (weight, bias) if fuse_b else (weight,))):
       # queued with the block's other weight gradients; the parameters are reported ready at the launch
       if want_b and not fuse_b:
-        db = dy2.sum(0, dtype=torch.float32)
-        if bias.grad is None:
-          bias.grad = db.to(bias.dtype)
-        else:
-          bias.grad.add_(db)
+        _add_bias_grad(bias, dy2)
         _notify(bias)
       return
     wgrad = fused.wgrad_accumulate_side_ if side else fused.wgrad_accumulate_
@@ -134,11 +143,7 @@ def _accumulate_dense_grads(weight, bias, dy2, x2):
     _notify(weight)
   if want_b:
     if not b_done:
-      db = dy2.sum(0, dtype=torch.float32)
-      if bias.grad is None:
-        bias.grad = db.to(bias.dtype)
-      else:
-        bias.grad.add_(db)
+      _add_bias_grad(bias, dy2)
     _notify(bias)
 
 
@@ -248,7 +253,7 @@ class _TiedLogitsFn(torch.autograd.Function):
       fused.accumulate_grad_(table.grad, torch.mm(dy.t(), x))
     db = None
     if bias is not None and bias.requires_grad:
-      db = dy.sum(0, dtype=torch.float32).to(bias.dtype)
+      db = (fused.colsum(dy) if dy.is_cuda else dy.sum(0, dtype=torch.float32)).to(bias.dtype)
     return dx, None, db
 
 
@@ -528,6 +533,27 @@ class MaskedLM(nn.Module):
     return logits.view(masked_positions.shape[0], masked_positions.shape[1], -1)
 
 
+class _AddRowBiasFn(torch.autograd.Function):
+  """x[rows, C] + bias[C]; the bias gradient is one pass of the HIP column-sum kernel (torch's reduction needs 22 us
+  for the [392, 512] logits of the patch-prediction head)."""
+
+  @staticmethod
+  def forward(ctx, x, bias):
+    ctx.bias_dtype = bias.dtype
+    return x + bias.to(x.dtype)
+
+  @staticmethod
+  def backward(ctx, dy):
+    dy2 = dy.reshape(-1, dy.shape[-1])
+    return dy, fused.colsum(dy2 if dy2.stride(1) == 1 else dy2.contiguous()).to(ctx.bias_dtype)
+
+
+def _add_row_bias(x, bias):
+  if x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and bias.requires_grad:
+    return _AddRowBiasFn.apply(x, bias)
+  return x + bias.to(x.dtype)
+
+
 class MaskedPP(nn.Module):
   """`src/modeling/layers/masked_patch_prediction_layer.py:58-98`: gather -> LN -> dense -> bias."""
 
@@ -550,7 +576,7 @@ class MaskedPP(nn.Module):
     x = _linear(x, self.dense_weight, self.dense_bias)
     if self.activation is not None:
       x = self.activation(x)
-    logits = (x + self.bias.to(x.dtype)).view(masked_positions.shape[0], masked_positions.shape[1], -1)
+    logits = _add_row_bias(x, self.bias).view(masked_positions.shape[0], masked_positions.shape[1], -1)
     return logits if self._output_type == 'logits' else F.log_softmax(logits.float(), -1)
 
 

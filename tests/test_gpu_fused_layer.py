@@ -464,3 +464,22 @@ def test_grad_clip_scale_matches_global_norm(pending):
     assert abs(norm - true) / true < 1e-5
     assert abs(scale - min(1.0, max_norm / (true + 1e-6)) * pending) / pending < 1e-5
   assert L.mmt_grad_clip_scale(3, ptrs, sizes, 1.0, 1.0, out.data_ptr(), None, None, 0, None) == -3
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('rows,C,pad', [(1024, 30522, 0), (392, 512, 0), (7, 33, 5), (1, 2, 0), (100, 1, 3)])
+def test_colsum_matches_fp64_sum(rows, C, pad, dtype):
+  """mmt_colsum (bias gradients dy.sum(0), any row stride / alignment) against an fp64 sum of the stored values; the
+  accumulate form adds to an existing fp32 buffer; two runs are bit-identical (fixed-order sums)."""
+  from mmt_amd import fused
+  g = torch.Generator(device='cuda').manual_seed(rows * 7 + C)
+  buf = torch.randn(rows, C + pad, device='cuda', generator=g).to(dtype)
+  x = buf[:, :C]
+  want = x.double().sum(0)
+  got = fused.colsum(x)
+  tol = 1e-5 * (1 + float(x.double().abs().sum(0).max()))
+  assert float((got.double() - want).abs().max()) < tol
+  acc = torch.full((C,), 3.0, device='cuda')
+  fused.colsum(x, out=acc)
+  assert float((acc.double() - 3.0 - want).abs().max()) < tol
+  assert torch.equal(got, fused.colsum(x))
