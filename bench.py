@@ -226,8 +226,14 @@ def main():
   if not on_gpu and args.mode != 'allreduce':
     sys.exit('bench.py: no GPU visible -- the hot path has no CPU fallback (only --mode allreduce runs on gloo/CPU)')
   dev = torch.device('cuda', local_rank) if on_gpu else torch.device('cpu')
-  if world > 1:
+  # MMT_FORCE_DIST=1 (rehearsal): one rank, but through the collective backend and the multi-rank reducer -- on a
+  # one-GPU box this is the only way to execute the RCCL path (init, async bucket all-reduces under backward, waits)
+  force_dist = world == 1 and os.environ.get('MMT_FORCE_DIST') == '1'
+  if world > 1 or force_dist:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if force_dist:
+      os.environ.setdefault('MASTER_PORT', str(_free_port()))
+      os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
     kw = {'device_id': dev} if backend == 'nccl' else {}
     dist.init_process_group(backend, **kw)
   if on_gpu:
@@ -238,12 +244,12 @@ def main():
       torch.cuda.synchronize()
 
   def barrier():
-    if world > 1:
+    if world > 1 or force_dist:
       dist.barrier()
     sync()
 
   ranks_seen = 1
-  if world > 1:        # every rank must be reachable through the collective backend before anything is timed
+  if world > 1 or force_dist:        # every rank must be reachable through the collective backend before anything is timed
     t = torch.ones(1, device=dev)
     dist.all_reduce(t)
     sync()
@@ -381,7 +387,7 @@ def main():
                                'radius 64 + 8 global tokens, bf16, per-GPU batch 4'
                                + (' -- SIDE MEASUREMENT with the 2-D relative ids of *_2d*.yaml (1 core layer, R=49)' if args.ids2d else ''),
                    'step': mode, 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': S,
-                   'parallelism': f'dp{world}', 'backend': backend if world > 1 else None,
+                   'parallelism': f'dp{world}', 'backend': backend if (world > 1 or force_dist) else None,
                    'ranks_seen': ranks_seen, **step_info},
         'attention_fwd': {'us_per_layer_call': round(attn_ms * 1e3, 2), 'tflops': roofline['mfma_tflops'],
                           'samples_per_s': round(B / (attn_ms * 1e-3), 1)},
@@ -394,7 +400,7 @@ def main():
         'cpu_baseline_train_step': cpu_step,
     }
     print(json.dumps(line), flush=True)
-  if world > 1:
+  if world > 1 or force_dist:
     dist.destroy_process_group()
 
 

@@ -8,8 +8,13 @@ import torch
 from . import configs, distribute, optimization, tasks
 
 
+def _exchanging(world: int) -> bool:
+  """More than one rank, or the one-rank rehearsal of the exchange machinery (MMT_FORCE_DIST=1, bench.py)."""
+  return world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized())
+
+
 def _exchange_label(world: int, bucket_mb: float) -> str:
-  if world == 1:
+  if not _exchanging(world):
     return 'none (1 GPU)'
   backend = torch.distributed.get_backend()
   name = 'RCCL (nccl backend)' if backend == 'nccl' else backend
@@ -35,7 +40,7 @@ def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.
                          'relative_att_num_core_layers': cfg.get('core', 0),     # > 0: 2-D ids (*_2d*.yaml)
                          'num_global_tokens': cfg['ng']},
       }})
-  strategy = distribute.DataParallelStrategy(torch.distributed.get_backend() if world > 1 else None)
+  strategy = distribute.DataParallelStrategy(torch.distributed.get_backend() if _exchanging(world) else None)
   task = tasks.PretrainingTask(exp.task, compute_dtype=dtype, num_replicas=world)
   torch.manual_seed(0)
   model = task.build_model().to(device)
@@ -72,7 +77,7 @@ def make_allreduce_bench(device, world: int, mbytes=None):
   chunk = 2_359_296                      # one 768 x 3072 weight
   sizes = [chunk] * (n // chunk) + ([n % chunk] if n % chunk else [])
   params = [torch.nn.Parameter(torch.zeros(s, device=device)) for s in sizes]
-  strategy = distribute.DataParallelStrategy(torch.distributed.get_backend() if world > 1 else None)
+  strategy = distribute.DataParallelStrategy(torch.distributed.get_backend() if _exchanging(world) else None)
   reducer = strategy.make_reducer(params, reduce='sum')
 
   def step():

@@ -81,6 +81,9 @@ class GradientBucketReducer:
       raise ValueError("reduce must be 'mean' or 'sum'")
     self.strategy, self.reduce = strategy, reduce
     self.world = strategy.num_replicas_in_sync
+    # MMT_FORCE_DIST=1: run the multi-rank machinery (ready hooks, bucketed async all-reduce, main-stream weight
+    # gradients, CU budget) with ONE rank -- the only way to execute the RCCL path on a one-GPU box
+    self.exchange = self.world > 1 or (strategy.backend is not None and os.environ.get('MMT_FORCE_DIST') == '1')
     self.params = [p for p in params if p.requires_grad]
     self.buckets: List[torch.Tensor] = []
     self.layout = []            # (param, bucket index, element offset) for flat optimizers
@@ -111,7 +114,7 @@ class GradientBucketReducer:
       self._pending.append(len(group))
     self._group_sizes = list(self._pending)
     self.armed = True
-    if self.world > 1:
+    if self.exchange:
       if self.params and self.params[0].is_cuda:
         # leave compute units to the RCCL kernels that run under backward (csrc/wgrad_gemm.hip)
         from . import _lib
@@ -171,7 +174,7 @@ class GradientBucketReducer:
     (`pending_scale`): `clip_by_global_norm(apply=False)` folds it into the factor a fused optimizer
     multiplies the gradients with, which saves one read-modify-write pass over every gradient."""
     self.pending_scale = 1.0
-    if self.world > 1:
+    if self.exchange:
       for gi, left in enumerate(self._pending):     # parameters that received no gradient
         assert left >= 0, 'gradient-ready accounting went negative'
         if left > 0:

@@ -162,3 +162,26 @@ def test_replicas_draw_different_dropout_masks():
   assert torch.equal(a[0], a[1]) and torch.equal(b[0], b[1])
   assert not torch.equal(a[0], a[2])
   assert not torch.equal(a[0], b[0])
+
+
+def test_rccl_path_executes_with_one_rank():
+  """`MMT_FORCE_DIST=1 python bench.py`: ONE rank, but through `init_process_group('nccl')`, the multi-rank reducer
+  (ready hooks, one async RCCL all-reduce per 48 MB bucket under backward, waits), the main-stream weight gradients
+  and the reduced CU budget -- the RCCL code path of BASELINE config 4 (`distribute_utils.py:97-188`,
+  `pretraining.py:273`) executed on real hardware, which the one-GPU box cannot do with more ranks.  The all-reduce
+  of ones must see exactly this rank, and the step must produce a finite throughput."""
+  import json, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, MMT_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  env.pop('MMT_DIST_BACKEND', None)
+  out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--steps', '3', '--warmup', '2', '--no-cpu-baseline'],
+                       env=env, capture_output=True, text=True, timeout=600)
+  assert out.returncode == 0, out.stderr[-2000:]
+  line = json.loads(out.stdout.strip().splitlines()[-1])
+  assert line['config']['backend'] == 'nccl' and line['config']['ranks_seen'] == 1
+  assert 'RCCL' in line['config']['grad_allreduce']
+  assert line['value'] > 0 and line['ms_per_step'] > 0
+  ar = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--mode', 'allreduce', '--steps', '3', '--warmup', '1'],
+                      env=env, capture_output=True, text=True, timeout=600)
+  assert ar.returncode == 0, ar.stderr[-2000:]           # asserts inside that every bucket holds the SUM over the ranks
+  assert json.loads(ar.stdout.strip().splitlines()[-1])['config']['backend'] == 'nccl'
