@@ -176,3 +176,10 @@ def test_config5_full_size_train_step_bf16(ng):
 def test_config3_full_size_train_step_bf16():
   """BASELINE config 3 (the bench workload) through the same closure bench.py times."""
   _full_config(dict(), torch.bfloat16)
+
+
+def test_config3_full_size_train_step_2d_ids_bf16():
+  """The config-3 workload with the 2-D relative ids of the reference's `*_2d*.yaml` experiments (one core layer,
+  relative_vocab_size 49: `MmtRelativePositionGenerator`, feature_utils.py:114-184) -- the lean 2-D attention kernels
+  inside the full train step (`bench.py --ids2d`)."""
+  _full_config(dict(R=49, core=1, P=63), torch.bfloat16)
