@@ -47,6 +47,12 @@ int mmt_ln_fwd(const mmt_rows_desc* desc, const void* x, const float* gamma, con
                void* y, float* mean, float* rstd, void* stream);
 
 /* dx, dgamma[H], dbeta[H] of mmt_ln_fwd (dgamma / dbeta are overwritten). */
+/* mmt_ln_bwd with a second incoming gradient: dx = dx_in + LayerNormBackward(dy) (dx_in may be NULL) -- the input of
+ * the first pre-activation block feeds both its LayerNorm and its residual sum (mmt_encoder.py:124-135); one kernel
+ * instead of autograd's extra add over [B*S, H]. */
+int mmt_ln_bwd_add(const mmt_rows_desc* desc, const void* dy, const void* x, const float* gamma,
+                   const float* mean, const float* rstd, const void* dx_in, void* dx, float* dgamma, float* dbeta,
+                   void* workspace, size_t workspace_bytes, void* stream);
 int mmt_ln_bwd(const mmt_rows_desc* desc, const void* dy, const void* x, const float* gamma,
                const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                void* workspace, size_t workspace_bytes, void* stream);

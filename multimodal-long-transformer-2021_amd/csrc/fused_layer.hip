@@ -575,11 +575,17 @@ int mmt_ln_fwd(const mmt_rows_desc* d, const void* x, const float* gamma, const 
 int mmt_ln_bwd(const mmt_rows_desc* d, const void* dy, const void* x, const float* gamma,
                const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta,
                void* ws, size_t ws_bytes, void* stream) {
+  return mmt_ln_bwd_add(d, dy, x, gamma, mean, rstd, nullptr, dx, dgamma, dbeta, ws, ws_bytes, stream);
+}
+
+int mmt_ln_bwd_add(const mmt_rows_desc* d, const void* dy, const void* x, const float* gamma,
+                   const float* mean, const float* rstd, const void* dx_in, void* dx, float* dgamma, float* dbeta,
+                   void* ws, size_t ws_bytes, void* stream) {
   if (int rc = check_rows(d, kMaxLnH)) return rc;
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) return lfail(MMT_E_INVALID, "mmt_ln_bwd: NULL argument");
   if (!ws || ws_bytes < mmt_layer_workspace_bytes(d)) return lfail(MMT_E_WORKSPACE, "mmt_ln_bwd: workspace too small");
   mmt::LayerParams p; fill(p, d);
-  p.b = dy; p.c = x; p.p1 = gamma; p.mean = mean; p.rstd = rstd; p.o1 = dx; p.part = (float*)ws;
+  p.a = dx_in; p.b = dy; p.c = x; p.p1 = gamma; p.mean = mean; p.rstd = rstd; p.o1 = dx; p.part = (float*)ws;
   p.nblocks = row_blocks(d);
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = launch_bwd<false, true>(p, d->dtype == MMT_BF16, st, p.nblocks);

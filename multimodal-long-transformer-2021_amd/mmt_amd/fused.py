@@ -138,6 +138,59 @@ def layer_norm(x, gamma, beta, eps=1e-12):
   return _LayerNormFn.apply(x, gamma, beta, eps)
 
 
+class _LayerNormKeepFn(torch.autograd.Function):
+  """(x, LayerNorm(x)): the input is handed on as an alias so that a consumer of BOTH (the first pre-activation
+  block: residual sum and LayerNorm of the embedding output) sends its two gradients back through ONE node --
+  dx = dx_alias + LayerNormBackward(dh) in one kernel (`mmt_ln_bwd_add`) instead of autograd's add over [B*S, H]."""
+
+  @staticmethod
+  def forward(ctx, x, gamma, beta, eps):
+    _check(x, gamma, beta)
+    shape = x.shape
+    x2 = x.reshape(-1, shape[-1]).contiguous()
+    gamma_p, beta_p = gamma, beta
+    gamma, beta = _f32(gamma), _f32(beta)
+    y = torch.empty_like(x2)
+    mean = torch.empty(x2.shape[0], dtype=torch.float32, device=x.device)
+    rstd = torch.empty_like(mean)
+    d = _desc(x2, eps)
+    with torch.cuda.device(x.device):
+      _lib.check(_lib.lib().mmt_ln_fwd(d, _p(x2), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), _stream(x)))
+    ctx.save_for_backward(x2, gamma, mean, rstd)
+    ctx.eps, ctx.shape = eps, shape
+    ctx.params = (gamma_p, beta_p)
+    return x.view_as(x), y.view(shape)
+
+  @staticmethod
+  def backward(ctx, dx_alias, dy):
+    x2, gamma, mean, rstd = ctx.saved_tensors
+    gamma_p, beta_p = ctx.params
+    if dy is None:
+      return dx_alias, None, None, None
+    dy2 = dy.reshape(x2.shape).contiguous()
+    din = None if dx_alias is None else dx_alias.reshape(x2.shape).contiguous()
+    dx = torch.empty_like(x2)
+    (dg, dg_direct), (db, db_direct) = _grad_target(gamma_p, gamma), _grad_target(beta_p, gamma)
+    direct = dg_direct and db_direct
+    if not direct:
+      dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+    d = _desc(x2, ctx.eps)
+    d.accumulate = int(direct)
+    d.defer_reduce = int(direct and side_stream_ok(gamma_p, beta_p))
+    ws = _ws(d, x2)
+    with torch.cuda.device(x2.device):
+      _lib.check(_lib.lib().mmt_ln_bwd_add(d, _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(din), _p(dx), _p(dg),
+                                           _p(db), _p(ws), ws.numel(), _stream(x2)))
+    if d.defer_reduce:
+      _reduce_on_side(d, 0, ws, (dg, db))
+    return dx.view(ctx.shape), _finish(gamma_p, dg, direct), _finish(beta_p, db, direct), None
+
+
+def layer_norm_keep(x, gamma, beta, eps=1e-12):
+  """(x_alias, LayerNorm(x)) -- use x_alias for every other consumer of x (see `_LayerNormKeepFn`)."""
+  return _LayerNormKeepFn.apply(x, gamma, beta, eps)
+
+
 class _ResidualBlockFn(torch.autograd.Function):
   """(x_new, h) = (x + Dropout(o + bias), LayerNorm(x_new)); h is None without gamma."""
 

@@ -413,7 +413,7 @@ class RelativeTransformerLayers(nn.Module):
     L = len(self.layers)
     p = self.layers[0].hidden_dropout_prob if training else 0.0
     first = self.layers[0].attention_layer_norm
-    h = fused.layer_norm(x, first.weight, first.bias, first.eps)
+    x, h = fused.layer_norm_keep(x, first.weight, first.bias, first.eps)    # x: alias, both gradients come back through one node
     for i, layer in enumerate(self.layers):
       o = layer.attention(h, training=training, dropout_seed=dropout_seed * 131 + i,
                           add_output_bias=False, **att_kw)
