@@ -409,11 +409,14 @@ def wgrad_accumulate_(dw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, dbias
 # stream when the backward pass ends (engine callback), and the caching allocator is told about the extra
 # stream (record_stream).  A data-parallel reducer calls `wait_side_streams()` right before it launches a
 # bucket's all-reduce (the collective is ordered against the current stream only).
-# MMT_WGRAD_SIDE_STREAM: 0 = never, 1 (default) = single-process runs only, 2 = also under a data-parallel
-# reducer.  The 2-rank rehearsal on one GPU over gloo is correct with it but ~25x slower per step (gloo's
-# CUDA staging path against a second stream), and RCCL cannot be rehearsed on the one-GPU box, so the
-# multi-GPU default stays on the single-stream path.
-_SIDE_MODE = int(os.environ.get('MMT_WGRAD_SIDE_STREAM', '1'))
+# MMT_WGRAD_SIDE_STREAM: 0 (default since the grouped launches) = never, 1 = single-process runs only, 2 = also under
+# a data-parallel reducer.  The side stream was worth 0.4 ms per step while every weight gradient was a launch of
+# its own with a 6- to 24-way split of K; with the block's four products in one launch (queued and launched on the
+# main stream as well, `wgrad_accumulate_deferred_`) the two paths measure the same (15.93 vs 15.98 ms over four
+# same-box pairs), and the single-stream path is the one a data-parallel run takes anyway -- so N = 1 and N > 1 time
+# the same kernels in the same order.  (The 2-rank rehearsal on one GPU over gloo is correct with mode 2 but ~25x
+# slower per step: gloo's CUDA staging path against a second stream.)
+_SIDE_MODE = int(os.environ.get('MMT_WGRAD_SIDE_STREAM', '0'))
 WGRAD_SIDE_STREAM = _SIDE_MODE != 0
 _SIDE = {}
 _side_pending = {}         # device -> id of the backward pass (graph task) whose end-of-backward join is queued
