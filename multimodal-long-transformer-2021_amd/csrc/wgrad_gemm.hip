@@ -413,8 +413,14 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_group_kernel(const WgradGrou
   while (j + 1 < g.n && t >= g.tiles_end[j]) ++j;
   if (j > 0) t -= g.tiles_end[j - 1];
   const WgradParams p = g.p[j];
-  const int tm = t / p.tiles_n;
-  wgrad_dma_body(p, ks, tm, t - tm * p.tiles_n);
+  // Tile order inside a problem: the SHORTER tile dimension runs fastest, so that the ~27 consecutive tiles one XCD
+  // works on at a time form a block as square as the problem allows -- e.g. the 3 x 12 tiles of the FFN output
+  // weight: 3 dy column blocks + 9 x column blocks per 27 tiles instead of 3 + 12 (fewer distinct operand
+  // blocks per 64-row step = fewer L2 fills).
+  int tm, tn;
+  if (p.tiles_m < p.tiles_n) { tn = t / p.tiles_m; tm = t - tn * p.tiles_m; }
+  else { tm = t / p.tiles_n; tn = t - tm * p.tiles_n; }
+  wgrad_dma_body(p, ks, tm, tn);
 }
 
 // dw[m][n] += sum_s slabs[s][m][n]   (fixed order: bitwise reproducible)
