@@ -238,37 +238,30 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, int ks, int
   const int n_steps = (k_end - k_begin) >> 6;
   if (n_steps <= 0) return;
 
-  // ---- DMA map: wave w issues instructions w*8 .. w*8+7 of the stage; instruction idx = (kslab*8 + tile8)*4 + rowgroup
+  // ---- DMA map: the staging LDS is a ring of four 32-row SLABS (8 tiles of 32 x 128 B each: dy tiles 0-3, x tiles
+  //      4-7).  Wave w loads tile w of every slab: four 1 KiB instructions (row groups of 8) per slab.
   const int drow = lane >> 3, dpos = lane & 7;                 // row inside the 8-row group, 16-byte position in the LDS row
-  const __bf16* gsrc[8];
-  int ldst[8];
+  const __bf16* gsrc[4];
+  int ldst[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int idx = wave * 8 + j;
-    const int kslab = idx >> 5, tile8 = (idx >> 2) & 7, rg = idx & 3;
-    const int row = rg * 8 + drow;                             // row inside the tile
+  for (int j = 0; j < 4; ++j) {
+    const int row = j * 8 + drow;                              // row inside the slab
     const int ch = (((dpos >> 2) ^ ((row >> 1) & 1)) << 2) | (dpos & 3);    // logical chunk stored at this LDS position
-    const long krow = k_begin + kslab * 32 + row;
-    gsrc[j] = tile8 < 4 ? p.dy + krow * p.ldy + m0 + tile8 * 64 + ch * 8
-                        : p.x + krow * p.ldx + n0 + (tile8 - 4) * 64 + ch * 8;
-    ldst[j] = idx * 1024;
+    const long krow = k_begin + row;
+    gsrc[j] = wave < 4 ? p.dy + krow * p.ldy + m0 + wave * 64 + ch * 8
+                       : p.x + krow * p.ldx + n0 + (wave - 4) * 64 + ch * 8;
+    ldst[j] = (wave * 4 + j) * 1024;
   }
-  const long astep = 64 * p.ldy, bstep = 64 * p.ldx;
+  const long slab_step = 32 * (wave < 4 ? p.ldy : p.ldx);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  // `part` < 0: all eight of this wave's DMA instructions; else instructions 2*part, 2*part+1.  Inside the main
-  // loop they are issued two per k-substep, between the MFMA groups: issued back to back, 64 x 1 KiB per
-  // workgroup overrun the memory pipe's queue and the waves that come last sit in the issue for ~2000 cycles
-  // (in-kernel timestamps: half a step) before they reach their MFMAs.  Worth ~2 %: a step stays at 3500-4000
-  // cycles because the matrix pipe (64 MFMAs per SIMD = 2048), the LDS (192 KiB of fragment reads + 64 KiB of
-  // DMA writes = 2048) and the DMA path (64 KiB at the ~32 B/clk it sustains = 2000) all need about the same
-  // time and overlap imperfectly; how the eight instructions are spread over the substeps makes no difference.
-  auto dma = [&](unsigned stage, int step, int part) {
+  constexpr int kSlabBytes = 8 * 4096;
+  // instructions 2*part, 2*part+1 of slab `sl` into ring slot sl & 3 (part < 0: all four).  In the main loop they go
+  // out two per k-substep, between the MFMA groups (back to back they overrun the memory pipe's queue)
+  auto dma = [&](int sl, int part) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 4; ++j) {
       if (part >= 0 && (j >> 1) != part) continue;
-      const int tile8 = ((wave * 8 + j) >> 2) & 7;
-      const __bf16* g = gsrc[j] + (long)step * (tile8 < 4 ? astep : bstep);
-      glds16(g, stage + ldst[j]);
+      glds16(gsrc[j] + (long)sl * slab_step, lds0 + (sl & 3) * kSlabBytes + ldst[j]);
     }
   };
 
@@ -290,17 +283,27 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, int ks, int
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int bch = tid & 31, brow0 = tid >> 5;
 
-  dma(lds0, 0, -1);
-  wait_dma();
-  __syncthreads();
-
-  for (int step = 0; step < n_steps; ++step) {
-    unsigned char* cur = smem + (step & 1) * kDmaStageBytes;
-    const bool more = step + 1 < n_steps;
+  // Ring schedule: three slabs are in flight ahead of the one being consumed (1.5 steps of 64 rows instead of 1 with
+  // two 64-row buffers: an HBM miss takes longer than one step).  Per slab: a COUNTED wait for this wave's own four
+  // instructions of the slab (the 8 of the two later slabs stay in flight), one raw barrier -- every wave's part has
+  // landed and every wave is done reading the slot that is refilled next -- then the refill and 16 MFMAs per wave.
+  const int n_slabs = 2 * n_steps;
+  dma(0, -1);
+  if (n_slabs > 1) dma(1, -1);
+  if (n_slabs > 2) dma(2, -1);
+  for (int sl = 0; sl < n_slabs; ++sl) {
+    const int behind = n_slabs - 1 - sl;                   // slabs issued after this one (at most 2 right now)
+    if (behind >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of the previous slab have returned
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* cur = smem + (sl & 3) * kSlabBytes;
+    const bool more = sl + 3 < n_slabs;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (more) dma(lds0 + ((step + 1) & 1) * kDmaStageBytes, step + 1, s);         // lands during this step's MFMAs
-      const unsigned char* slab = cur + (s >> 1) * (8 * 4096) + (s & 1) * 2048;
+    for (int s = 0; s < 2; ++s) {
+      if (more) dma(sl + 3, s);                            // into the slot of slab sl - 1: every wave has left it
+      const unsigned char* slab = cur + s * 2048;
       bf16x8 af[2], bfr[4];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -326,19 +329,17 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, int ks, int
     }
     if (do_bias) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int row = brow0 + 16 * v;                  // 0..63
-        const int rt = row & 31, t4 = bch >> 3, c8 = bch & 7;
-        const unsigned char* src = cur + (row >> 5) * (8 * 4096) + t4 * 4096 + rt * 128 +
-                                   ((((c8 >> 2) ^ ((rt >> 1) & 1))) << 6) + (c8 & 3) * 16;
+      for (int v = 0; v < 2; ++v) {
+        const int rt = brow0 + 16 * v;                   // 0..31: row inside the slab
+        const int t4 = bch >> 3, c8 = bch & 7;
+        const unsigned char* src = cur + t4 * 4096 + rt * 128 + ((((c8 >> 2) ^ ((rt >> 1) & 1))) << 6) + (c8 & 3) * 16;
         const bf16x8 t = *reinterpret_cast<const bf16x8*>(src);
 #pragma unroll
         for (int j = 0; j < 8; ++j) bsum[j] += (float)t[j];
       }
     }
-    wait_dma();                            // the DMA into the other buffer has landed
-    __syncthreads();
   }
+  __syncthreads();
 
   if (do_bias) {       // 16 row groups x 256 columns through the (now idle) staging LDS, fixed order
     float* red = reinterpret_cast<float*>(smem);
