@@ -51,9 +51,6 @@ __device__ __forceinline__ void wave_lds_sync() {
 // LDS float += v (no return value).  The rows of the per-wave dRel table are lane-private, so the only accesses
 // that meet on one address are this lane's own, and LDS executes a wave's instructions in order.
 __device__ __forceinline__ void lds_add_f32(int addr, float v) {
-#ifdef MMT_ABL_NOADD
-  asm volatile("" : : "v"(addr), "v"(v) : "memory"); return;
-#endif
   asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(v) : "memory");
 }
 
