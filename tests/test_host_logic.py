@@ -193,3 +193,22 @@ def test_gradient_reduce_mode_follows_scale_loss(monkeypatch):
   assert tasks.gradient_reduce_mode(C()) == 'mean'
   monkeypatch.setenv('MMT_REFERENCE_SUM', '1')
   assert tasks.gradient_reduce_mode(C()) == 'sum'
+
+
+def test_attention_pattern_normalizes_listed_global_sets():
+  """Host logic of `mmt_mask_desc.global_index` (ABI 2): sorted, de-duplicated; a contiguous run becomes the range
+  form (structured kernels), a scattered list stays a list; negative positions are refused."""
+  import mmt_amd
+  P = mmt_amd.AttentionPattern
+  run = P(local_radius=8, global_index=(12, 10, 11, 11)).normalized()
+  assert run.global_index is None and (run.global_start, run.n_global) == (10, 3)
+  scat = P(local_radius=8, global_index=(40, 3, 3, 17)).normalized()
+  assert scat.global_index == (3, 17, 40) and scat.n_global == 3
+  empty = P(local_radius=8, global_index=()).normalized()
+  assert empty.global_index is None and empty.n_global == 0
+  plain = P(local_radius=8, global_start=5, n_global=2)
+  assert plain.normalized() is plain
+  with pytest.raises(ValueError):
+    P(global_index=(-1, 4)).normalized()
+  with pytest.raises(ValueError):
+    scat.to_desc(None)                      # a listed set needs the device its index list lives on
