@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, (Rp == 64 && REL == 2) ? 2 : 3) void attn_fwd_
   bool rows_item;
   {
     int blk;
-    plane_major_map(blockIdx.x, p.B * p.N, per_bn, nqb, bn, blk);
+    plane_major_map(blockIdx.x, p.B * p.N, per_bn, p.rows_only ? 0 : nqb, bn, blk);
     rows_item = blk < per_bn;
     if (rows_item) {
       const int item = blk * 4 + wave;
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256, (Rp == 64 && REL == 2) ? 2 : 3) void attn_fwd_
 
 hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st) {
   const int per_bn = (p.n_chunks * p.n_rowblk + 3) / 4;
-  dim3 grid(p.n_band_blocks + per_bn * p.B * p.N);
+  dim3 grid((p.rows_only ? 0 : p.n_band_blocks) + per_bn * p.B * p.N);
   const int rel = p.R > 0 ? p.pat.id_mode : 0;
   if (rel == 2) {                    // 2-D ids: table width chosen by the host (lean_rp), one look-up table per wave
     const int n2 = 2 * p.pat.r + 3, lut_bytes = 4 * 4 * ((n2 * n2 + 15) & ~15);

@@ -32,11 +32,17 @@ struct FwdParams {
   int n_band_blocks;  // B*N*ceil(S/128): blocks before the global-row items
   int perm_1d;        // 1-D ids with R >= 2m+1: table columns permuted, fast path allowed
   int lean_rp;        // lean 2-D path: table width (32 | 64) that holds every id that can contribute
+  int rows_only;      // lean band kernel: launch holds the global-row items only (the window kernel produced the band rows)
+  int tstride;        // window kernel: row stride (floats) of the per-wave relative-score table
+  long long* dbg;     // -DMMT_STAMP diagnostic builds only: in-kernel s_memtime stamps (never set in the product)
+  int dbg_mode, dbg_sleep;   // -DMMT_STAMP builds only: ablations (1 = no tile loop, 2 = no DMA), start delay of the second resident round
 };
 
 hipError_t launch_attn_fwd(const FwdParams& p, int mode, bool bf16, hipStream_t st);
 hipError_t launch_rows_combine(const FwdParams& p, bool bf16, hipStream_t st);
 hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st);   // attn_fwd_band.hip
+hipError_t launch_attn_fwd_win_bf16(const FwdParams& p, hipStream_t st);    // attn_fwd_win.hip
+int fwd_win_lds_bytes(int ng, int tstride);
 
 struct BwdParams {
   const void *q, *k, *v, *emb, *bias, *out, *dout;

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "attn_kernels.h"
@@ -191,6 +192,32 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   p.lean_rp = lean2d_width(p.pat, desc->R, dense);
   const bool lean = bf16 && (p.pat.id_mode == 0 || p.perm_1d || p.lean_rp);   // attn_fwd_band.hip
   p.part_scale = (lean && p.drop_thresh) ? p.inv_keep : 1.f;
+  // window kernel (attn_fwd_win.hip): K / V staged once per workgroup, global keys as a peeled quarter-tile step,
+  // rows of up to 16 global tokens by flipped-orientation workgroups of the same launch (no workspace, no combine
+  // launch).  Shapes it does not cover, or whose LDS need leaves one workgroup per CU, stay with the per-wave staging
+  // kernel.  MMT_FWD_WIN=0 turns it off, =2 takes it whenever the shape is covered (the tests run both).
+  const char* win_env = std::getenv("MMT_FWD_WIN");          // read per call: the tests switch it
+  const int win_mode = win_env ? std::atoi(win_env) : 1;
+  p.tstride = p.pat.id_mode == 0 ? 0 : (2 * p.pat.m + 1 <= 25 ? 26 : 34);
+#ifdef MMT_STAMP
+  if (const char* v = std::getenv("MMT_DBG_PTR")) p.dbg = reinterpret_cast<long long*>(std::strtoull(v, nullptr, 0));
+  if (const char* v = std::getenv("MMT_DBG_MODE")) p.dbg_mode = std::atoi(v);
+  if (const char* v = std::getenv("MMT_DBG_SLEEP")) p.dbg_sleep = std::atoi(v);
+#endif
+  const bool win_ok = lean && !p.lean_rp && desc->R <= 32 && p.pat.radius <= 64 && p.pat.ng <= 128;
+  const bool win = win_ok && win_mode != 0 && (win_mode == 2 || mmt::fwd_win_lds_bytes(p.pat.ng, p.tstride) <= 81920);
+  if (win) {
+    // rows of the global tokens: at most 16 -> extra workgroups of the window launch (8 rows each, no workspace, no
+    // combine launch); more -> the 32-row items of the per-wave kernel + combine, as a launch of their own
+    const bool rows_in_win = pl.split_rows && p.pat.ng <= 16;
+    const int n_rowblk_items = p.n_rowblk;
+    p.n_rowblk = rows_in_win ? (p.pat.ng + 7) / 8 : 0;
+    e = mmt::launch_attn_fwd_win_bf16(p, st);
+    if (e != hipSuccess) return fail(MMT_E_LAUNCH, "window forward launch: %s", hipGetErrorString(e));
+    if (!pl.split_rows || rows_in_win) return MMT_OK;
+    p.n_rowblk = n_rowblk_items;
+    p.rows_only = 1;
+  }
   e = lean ? mmt::launch_attn_fwd_band_bf16(p, st) : mmt::launch_attn_fwd(p, mmt::kBand, bf16, st);
   if (e != hipSuccess) return fail(MMT_E_LAUNCH, "band forward launch: %s", hipGetErrorString(e));
   if (pl.split_rows) {

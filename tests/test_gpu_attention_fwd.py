@@ -103,6 +103,44 @@ def test_structured_pattern(cfg, dtype):
   run_case(dtype=dtype, dense=False, **cfg)
 
 
+@pytest.mark.parametrize('win', ['0', '2'], ids=['per-wave', 'window'])
+@pytest.mark.parametrize('cfg', [
+    dict(B=2, S=256, N=2, R=32, radius=16, g0=200, ng=8, m=12),
+    dict(B=2, S=300, N=2, R=32, radius=64, g0=251, ng=8, m=12, valid=[300, 211]),     # ragged, odd global start
+    dict(B=1, S=700, N=3, R=32, radius=64, g0=333, ng=16, m=12),                      # two groups of global keys / rows
+    dict(B=1, S=700, N=2, R=32, radius=40, g0=100, ng=5, m=7),                        # radius not a tile multiple
+    dict(B=1, S=640, N=2, R=25, radius=64, g0=630, ng=3, m=12),                       # globals in the last tile
+    dict(B=1, S=520, N=2, R=0, radius=64, g0=0, ng=8),                                # no relative term
+    dict(B=1, S=512, N=2, R=41, radius=64, g0=400, ng=8, m=20),                       # wider table (window kernel only when forced)
+    dict(B=2, S=64, N=1, R=9, radius=8, g0=10, ng=2, valid=[0, 64]),
+    dict(B=1, S=20, N=2, R=9, radius=4, g0=0, ng=1),
+    dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),
+], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'm')))
+def test_both_forward_kernels(cfg, win, monkeypatch):
+  """The per-wave kernel (attn_fwd_band.hip) and the window kernel (attn_fwd_win.hip: shared K / V window, peeled
+  global keys, flipped global rows) on the same cases, each against the oracle; MMT_FWD_WIN picks the kernel
+  (0 = per-wave, 2 = window whenever the shape is covered; the default takes the window kernel when two of its
+  workgroups fit a CU)."""
+  monkeypatch.setenv('MMT_FWD_WIN', win)
+  run_case(dtype=torch.bfloat16, dense=False, **cfg)
+
+
+def test_forward_kernels_share_the_dropout_mask(monkeypatch):
+  """Same seed, same keep decisions: the two bf16 forward kernels agree to output rounding with dropout on (the keep
+  mask itself is checked against its restatement in test_gpu_attention_bwd.py)."""
+  import mmt_amd
+  B, S, N, R = 1, 1024, 2, 32
+  q, k, v, emb, bias = (torch.from_numpy(bf16_round(x)).cuda().bfloat16() for x in attention_inputs(B, S, N, R, seed=11))
+  pat = mmt_amd.AttentionPattern(local_radius=64, global_start=771, n_global=8, id_mode=1, max_dist=12)
+  outs = []
+  for win in ('0', '2'):
+    monkeypatch.setenv('MMT_FWD_WIN', win)
+    o, lse = mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat, dropout_p=0.25, dropout_seed=77)
+    outs.append((o.float().cpu().numpy(), lse.cpu().numpy()))
+  assert np.abs(outs[0][0] - outs[1][0]).max() < BF16_TOL
+  assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-3
+
+
 def test_online_softmax_rescale_is_exercised():
   """A late key with a much larger score forces the running-max rescale (guide rule 26)."""
   import mmt_amd
