@@ -316,7 +316,7 @@ def main():
                      'ranks_seen': ranks_seen, 'parallelism': f'dp{world}', **step_info},
           'bus_bandwidth_GBps': round(busbw, 2),
           'xgmi_ring_frac': round(busbw / XGMI_LINK_GBS, 4) if backend == 'nccl' else None}), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
       dist.destroy_process_group()
     return
 

@@ -1,0 +1,52 @@
+// Host-only stand-ins for the kernel launchers, for the sanitizer build of the C-ABI shim (`make asan`): they launch
+// nothing, check that every workspace pointer the shim derived lies inside the caller's workspace, and record what
+// was asked for so that the driver can assert on it.  CPU only -- never built into libmmt_attn.so.
+#include <cstdio>
+#include <cstdlib>
+
+#include "../attn_kernels.h"
+
+extern "C" {
+const unsigned char* g_ws_lo = nullptr;
+const unsigned char* g_ws_hi = nullptr;
+int g_launches = 0;
+int g_last_kind = 0;   // 1 fwd general, 2 fwd band, 3 fwd window, 4 rows combine, 5 bwd, 6 side inputs
+}
+
+namespace {
+void inside(const void* p, size_t bytes, const char* what) {
+  if (!p) return;
+  const unsigned char* b = static_cast<const unsigned char*>(p);
+  if (b < g_ws_lo || b + bytes > g_ws_hi) {
+    std::fprintf(stderr, "asan driver: %s [%p, +%zu) outside the workspace [%p, %p)\n", what, p, bytes, (const void*)g_ws_lo, (const void*)g_ws_hi);
+    std::abort();
+  }
+}
+}  // namespace
+
+namespace mmt {
+hipError_t launch_attn_fwd(const FwdParams& p, int, bool, hipStream_t) {
+  ++g_launches; g_last_kind = 1;
+  const size_t slots = (size_t)p.B * p.N * p.n_rowblk * p.n_chunks;
+  inside(p.part_o, slots * 32 * 64 * 4, "part_o");
+  inside(p.part_ml, slots * 64 * 4, "part_ml");
+  return hipSuccess;
+}
+hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st) { hipError_t e = launch_attn_fwd(p, 0, true, st); g_last_kind = 2; return e; }
+hipError_t launch_attn_fwd_win_bf16(const FwdParams&, hipStream_t) { ++g_launches; g_last_kind = 3; return hipSuccess; }
+int fwd_win_lds_bytes(int ng, int tstride) { return 65536 + (ng ? (2 * ((ng + 7) / 8) + 1) * 1024 : 0) + 512 * tstride; }
+hipError_t launch_rows_combine(const FwdParams&, bool, hipStream_t) { ++g_launches; g_last_kind = 4; return hipSuccess; }
+hipError_t launch_attn_bwd(const BwdParams& p, int, bool, hipStream_t) {
+  ++g_launches; g_last_kind = 5;
+  const size_t bn = (size_t)p.B * p.N, slots = bn * p.n_gblk * p.n_chunks;
+  inside(p.delta, bn * p.S * 4, "delta");
+  inside(p.relfar, bn * p.S * 2 * 4, "relfar");
+  inside(p.drel, bn * (size_t)p.pat.ng * p.Rp * 4, "drel");
+  inside(p.part_dq, slots * 32 * 64 * 4, "part_dq");
+  inside(p.part_dtab, slots * 32 * p.Rp * 4, "part_dtab");
+  inside(p.part_dkv, slots * 2 * 32 * 64 * 4, "part_dkv");
+  inside(p.part_red, bn * ((p.S + 127) / 128) * 4 * ((size_t)p.Rp * 64 + p.Rp) * 4, "part_red");
+  return hipSuccess;
+}
+hipError_t launch_side_inputs(const SideParams&, hipStream_t) { ++g_launches; g_last_kind = 6; return hipSuccess; }
+}  // namespace mmt

@@ -107,14 +107,17 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
 }
 
 // 2-D ids on the lean (bf16, structured pattern) kernels: table width that holds every id that can contribute --
-// image ids < (2r+1)^2 + 8, text ids <= 2m, never more than R (ids >= R contribute 0 under the one-hot lookup,
-// SURVEY App. B q1; the two cross-modal part ids are >= P^2 + 8 + 2m + 1 > any table here).  0 = not eligible
-// (the general kernels of attn_fwd.hip / attn_bwd.hip take the call).
+// image ids < (2r+1)^2 + 8, text ids <= 2m, and the two cross-modal part ids P^2 + 8 + 2m + 1 (+ 1) WHEN they are
+// below R (small images: P = 4, m = 3 gives 31 / 32 against R = 49); never more than R (ids >= R contribute 0 under
+// the one-hot lookup).  0 = not eligible (the general kernels of attn_fwd.hip / attn_bwd.hip take
+// the call).
 int lean2d_width(const mmt::PatternDev& pat, int R, bool dense) {
   if (dense || pat.id_mode != MMT_IDS_2D || R <= 0) return 0;
   const int d = 2 * pat.r + 1, n2 = d + 2;
   if (n2 * n2 > 256) return 0;                       // look-up table of the clamped (dx, dy) grid
-  const int need = std::min(R, std::max(d * d + 8, 2 * pat.m + 1));
+  int need = std::max(d * d + 8, 2 * pat.m + 1);
+  if (pat.image_part < R) need = std::max(need, pat.text_part + 1);       // the part ids index real table rows
+  need = std::min(R, need);
   return need <= 32 ? 32 : (need <= 64 ? 64 : 0);
 }
 

@@ -155,6 +155,25 @@ class MmtPretrainDataConfig(MmtDataConfig):  # pretrain_dataloader.py:29-42
 
 
 @dataclasses.dataclass
+class MmtClassificationDataConfig(MmtDataConfig):   # classification_dataloader.py:30-34
+  negative_positive_ratio: int = 1
+  pos_weight: float = 1.0
+
+
+@dataclasses.dataclass
+class MmtRetrievalDataConfig(MmtDataConfig):        # retrieval_dataloader.py:31-43
+  # image and text records stored separately: all combinations are enumerated on the fly
+  image_input_path: str = ''
+  text_input_path: str = ''
+  num_image_examples: int = 0
+  num_text_examples: int = 0
+  negative_positive_ratio: int = 1
+  pos_weight: float = 1.0
+  drop_remainder: bool = False
+  include_image_text_index: bool = True
+
+
+@dataclasses.dataclass
 class PretrainingTaskConfig(Config):         # pretraining.py:42-48
   model: PretrainModelConfig = dataclasses.field(default_factory=PretrainModelConfig)
   scale_loss: bool = False
@@ -163,6 +182,10 @@ class PretrainingTaskConfig(Config):         # pretraining.py:42-48
       default_factory=lambda: MmtPretrainDataConfig(is_training=False))
   init_checkpoint: str = ''
   micro_batch_size: int = 64     # BATCH_SIZE_PER_REPLICA, pretraining.py:39 (App. B q7)
+  # Build-defined: how data-parallel replicas' gradients combine when scale_loss is False -- 'mean' (default) or
+  # 'sum' = what the reference's optimizer literally applies (pretraining.py:273).  With scale_loss
+  # the reference's own loss / replicas makes the SUM the mean, and this field is not consulted.
+  gradient_reduction: str = 'mean'
 
 
 @dataclasses.dataclass
@@ -175,6 +198,7 @@ class ClassificationConfig(Config):          # classification.py:40-52
   init_checkpoint: str = ''
   init_cls_pooler: bool = False
   metric_type: str = 'accuracy'
+  gradient_reduction: str = 'mean'   # as PretrainingTaskConfig.gradient_reduction (classification.py:200-210)
 
 
 @dataclasses.dataclass
@@ -203,6 +227,11 @@ class TrainerConfig(Config):
   max_to_keep: int = 5
   validation_interval: int = 1000
   validation_steps: int = -1
+  # TFM `TrainerConfig` keys the fine-tune YAMLs set (itm_2d_from_vit.yaml:84-86): accepted and carried; exporting a
+  # best checkpoint needs the validation loop's metric of that name
+  best_checkpoint_export_subdir: str = ''
+  best_checkpoint_eval_metric: str = ''
+  best_checkpoint_metric_comp: str = 'higher'
   optimizer_config: OptimizerConfig = dataclasses.field(default_factory=OptimizerConfig)
 
   def override(self, values, strict=False, _path=''):
@@ -267,9 +296,9 @@ def mmt_pretraining() -> ExperimentConfig:       # pretraining_experiments.py:50
                     'task.validation_data.is_training != None'])
 
 
-def _finetune(lr=3e-5) -> ExperimentConfig:
+def _finetune(data_cls, lr=3e-5) -> ExperimentConfig:
   cfg = ExperimentConfig(
-      task=ClassificationConfig(),
+      task=ClassificationConfig(train_data=data_cls(), validation_data=data_cls(is_training=False)),
       trainer=TrainerConfig(optimizer_config=OptimizerConfig(initial_learning_rate=lr)),
       restrictions=['task.train_data.is_training != None',
                     'task.validation_data.is_training != None'])
@@ -279,12 +308,12 @@ def _finetune(lr=3e-5) -> ExperimentConfig:
 
 @register_config_factory('mmt/classification')
 def mmt_classification() -> ExperimentConfig:    # finetuning_experiments.py:25-60
-  return _finetune()
+  return _finetune(MmtClassificationDataConfig)
 
 
 @register_config_factory('mmt/retrieval')
 def mmt_retrieval() -> ExperimentConfig:         # finetuning_experiments.py:63-98
-  return _finetune()
+  return _finetune(MmtRetrievalDataConfig)
 
 
 def parse_configuration(experiment: str, config_files=(), params_override: Optional[str] = None,

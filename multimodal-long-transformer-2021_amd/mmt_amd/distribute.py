@@ -138,6 +138,9 @@ class GradientBucketReducer:
     self._handles = []
     self._ready = set()
     self.armed = True
+    # a backward that raised may have left parameters marked "product still queued": start every step clean
+    for p in self._bucket_of:
+      p._mmt_grad_deferred = False
 
   def set_armed(self, armed: bool):
     """With gradient accumulation over micro-batches only the LAST backward may launch the

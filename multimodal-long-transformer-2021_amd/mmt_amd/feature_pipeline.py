@@ -78,6 +78,33 @@ def make_matching_features(features: Dict[str, torch.Tensor], image_keys: torch.
   return out
 
 
+def matching_batch_size(data_config, batch_size_per_replica: int) -> int:
+  """Examples the matching step needs in hand so that no roll creates a false negative
+  (`MmtClassificationDataLoader.load`, src/data/classification_dataloader.py:132-137)."""
+  max_shift = int(data_config.negative_positive_ratio) + int(data_config.min_shift)
+  return (max_shift // batch_size_per_replica + 2) * batch_size_per_replica
+
+
+def make_matching_features_from_config(data_config, features: Dict[str, torch.Tensor],
+                                       image_keys: torch.Tensor) -> Dict[str, torch.Tensor]:
+  """`get_matching_fn(config, batch, config.negative_positive_ratio)` of the classification loader
+  (classification_dataloader.py:138-140): the data config's `negative_positive_ratio` and `min_shift` drive the
+  in-batch negatives (pretraining fixes the ratio at 1, pretrain_dataloader.py:184)."""
+  return make_matching_features(features, image_keys,
+                                negative_positive_ratio=int(getattr(data_config, 'negative_positive_ratio', 1)),
+                                min_shift=int(data_config.min_shift))
+
+
+def make_retrieval_labels(features: Dict[str, torch.Tensor], pos_weight: float = 1.0) -> Dict[str, torch.Tensor]:
+  """`get_retrieval_label_fn` (src/data/data_utils.py:744-760): label 1 where the image is the text's ground-truth
+  image, weight `pos_weight` on those pairs and 1 elsewhere (`MmtRetrievalDataConfig.pos_weight`)."""
+  label = (features['image_index'] == features['gt_image_index']).to(torch.int32)
+  out = dict(features)
+  out['label_ids'] = label
+  out['label_weights'] = label.to(torch.float32) * (float(pos_weight) - 1.0) + 1.0
+  return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # MLM / MPP masking (`get_masking_fn` -> `make_mlm_and_mpp_features`, src/data/data_utils.py:383-639),
 # batched on the device.  The reference calls tf_text.mask_language_model with a RandomItemSelector and a

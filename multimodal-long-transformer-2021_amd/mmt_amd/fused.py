@@ -451,9 +451,18 @@ def _join_side_streams():
   _side_pending.clear()
 
 
+_GRAPH_TASK_ID = getattr(torch._C, '_current_graph_task_id', None)
+
+
 def _graph_task_id():
-  fn = getattr(torch._C, '_current_graph_task_id', None)
-  return fn() if fn is not None else -1
+  return _GRAPH_TASK_ID() if _GRAPH_TASK_ID is not None else -1
+
+
+def grouping_is_safe() -> bool:
+  """The queues of grouped weight-gradient products tell a new backward pass from a stale one by autograd's graph-task
+  id.  Without that symbol every pass would look alike and products left behind by a backward that raised would be
+  launched (with dead operands) by the next one: fail closed -- no grouping, every product launched on its own."""
+  return _GRAPH_TASK_ID is not None
 
 
 def side_stream_ok(*params) -> bool:
@@ -468,6 +477,8 @@ def side_stream_ok(*params) -> bool:
 def _wgrad_groupable(dw, dy, x, dbias) -> bool:
   K, M = dy.shape
   N = x.shape[1]
+  if not grouping_is_safe():
+    return False
   return (dw.is_cuda and dw.dtype == torch.float32 and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
           and dw.shape == (M, N) and x.shape[0] == K and M % 256 == 0 and N % 256 == 0 and K % 64 == 0 and K > 0
           and dw.stride(1) == 1 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.stride(0) % 8 == 0
@@ -636,11 +647,14 @@ _WGRAD_WS = {}
 
 
 def _wgrad_ws(device, nbytes):
-  """One grow-only scratch buffer per device for the split-K slabs (stream-ordered reuse)."""
-  buf = _WGRAD_WS.get(device)
+  """One grow-only scratch buffer per (device, stream) for the split-K slabs: a buffer is only ever used on the stream
+  it was allocated on, so its reuse -- and the release of the one it replaces when it grows -- is stream-ordered even
+  when main-stream and side-stream launches (MMT_WGRAD_SIDE_STREAM) interleave."""
+  key = (device, torch.cuda.current_stream(device).cuda_stream)
+  buf = _WGRAD_WS.get(key)
   if buf is None or buf.numel() < nbytes:
     buf = torch.empty((max(nbytes, 16),), dtype=torch.uint8, device=device)
-    _WGRAD_WS[device] = buf
+    _WGRAD_WS[key] = buf
   return buf
 
 

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import dataclasses
 import math
+import weakref
 from typing import Optional
 
 import torch
@@ -92,11 +93,17 @@ _DENSE_CACHE = {}
 
 def _materialized(pattern: 'AttentionPattern', valid_len, B: int, S: int, device):
   """(att_mask, relative_att_ids) int32 [B,S,S] of a pattern with a listed global set, through `mmt_side_inputs`;
-  the last result is kept, so that the layers of one encoder pass (same pattern, same valid_len tensor) share it."""
-  key = (pattern, B, S, str(device), None if valid_len is None else (valid_len.data_ptr(), valid_len._version))
+  the last result is kept, so that the layers of one encoder pass (same pattern, same valid_len tensor) share it.
+  The entry is tied to the valid_len tensor OBJECT (a weak reference + its version counter), never to its address:
+  a later batch's tensor that the caching allocator places at the same address is a different object and misses;
+  when the tensor dies the entry (two B*S*S int32 tensors) is dropped with it."""
+  key = (pattern, B, S, str(device))
   hit = _DENSE_CACHE.get('last')
   if hit is not None and hit[0] == key:
-    return hit[1], hit[2]
+    ref, ver = hit[3]
+    if (valid_len is None and ref is None) or (ref is not None and valid_len is not None and ref() is valid_len
+                                               and ver == valid_len._version):
+      return hit[1], hit[2]
   if any(i >= S for i in pattern.global_index):
     raise ValueError('global_index position outside the sequence')
   img = valid_len if valid_len is not None else torch.full((B,), S, dtype=torch.int32, device=device)
@@ -107,8 +114,19 @@ def _materialized(pattern: 'AttentionPattern', valid_len, B: int, S: int, device
   with torch.cuda.device(device):
     _lib.check(_lib.lib().mmt_side_inputs(desc, B, S, img.data_ptr(), txt.data_ptr(), 1, mask.data_ptr(),
                                           None if ids is None else ids.data_ptr(), None, _stream_ptr(device)))
-  _DENSE_CACHE['last'] = (key, mask, ids)
+  if valid_len is None:
+    tie = (None, 0)
+  else:
+    tie = (weakref.ref(valid_len, lambda _r: _DENSE_CACHE.pop('last', None) if _DENSE_CACHE.get('last', (None,) * 4)[3][0] is _r else None),
+           valid_len._version)
+  _DENSE_CACHE['last'] = (key, mask, ids, tie)
   return mask, ids
+
+
+def clear_pattern_cache() -> None:
+  """Drops the cached dense side inputs of listed global sets (and the device copies of their index lists)."""
+  _DENSE_CACHE.clear()
+  _INDEX_LISTS.clear()
 
 
 def _resolve_pattern(pattern, att_mask, rel_ids, valid_len, q):

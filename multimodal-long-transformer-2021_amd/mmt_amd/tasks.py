@@ -35,12 +35,15 @@ def gradient_reduce_mode(task_config) -> str:
   The reference's optimizer SUMs the replicas' gradients (`pretraining.py:273`).  With
   `scale_loss=True` each replica differentiates `loss / num_replicas` (`pretraining.py:286-296`), so
   the SUM is the mean-of-replicas gradient: 'sum'.  With the default `scale_loss=False` the reference
-  applies world x the mean; this build averages instead ('mean') unless
-  MMT_REFERENCE_SUM=1 asks for the reference's literal behaviour."""
-  import os
+  applies world x the mean; this build averages instead unless the task config says
+  `gradient_reduction: sum` -- a field of `PretrainingTaskConfig` / `ClassificationConfig` (YAML key
+  `task.gradient_reduction`), the reference's literal behaviour."""
   if getattr(task_config, 'scale_loss', False):
     return 'sum'
-  return 'sum' if os.environ.get('MMT_REFERENCE_SUM') else 'mean'
+  mode = getattr(task_config, 'gradient_reduction', 'mean')
+  if mode not in ('mean', 'sum'):
+    raise ValueError(f"task.gradient_reduction must be 'mean' or 'sum', got {mode!r}")
+  return mode
 
 
 def _compute_dtype(runtime_dtype: Optional[str]) -> torch.dtype:

@@ -46,6 +46,46 @@ def test_struct_layout_matches_header(lib):
   assert ctypes.sizeof(lib.MaskDesc) == 8 + 7 * 4 + 4 + 8     # pointer + 7 ints (padded to 8) + the ABI-2 index pointer
 
 
+def test_integration_document_stub_matches_the_binding(lib):
+  """The ctypes stub printed in INTEGRATION.md section 2 is what a maintainer copies: its field lists and ctypes
+  types must be the ones of mmt_amd/_lib.py (which test_struct_layout_matches_header ties to the header), and the
+  structs built from the document must have the binding's sizes (MaskDesc 48 bytes since ABI 2)."""
+  doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+  sec = doc[doc.index('## 2. ctypes stub'):doc.index('## 3.')]
+  code = sec[sec.index('```python') + len('```python'):]
+  code = code[:code.index('```')]
+  # execute the two class definitions only (no library load, no call)
+  defs = code[code.index('class MaskDesc'):code.index('lib.mmt_attn_fwd.restype')]
+  ns = {'ctypes': ctypes}
+  exec(defs, ns)
+  for name in ('MaskDesc', 'AttnDesc'):
+    doc_fields = [(f[0], f[1]) for f in ns[name]._fields_]
+    lib_fields = [(f[0], f[1]) for f in getattr(lib, name)._fields_]
+    assert [f[0] for f in doc_fields] == [f[0] for f in lib_fields], name
+    for (n, t_doc), (_, t_lib) in zip(doc_fields, lib_fields):
+      if n == 'mask':
+        assert ctypes.sizeof(t_doc) == ctypes.sizeof(t_lib)
+      else:
+        assert t_doc is t_lib or (ctypes.sizeof(t_doc), t_doc._type_ if hasattr(t_doc, '_type_') else None) == \
+            (ctypes.sizeof(t_lib), t_lib._type_ if hasattr(t_lib, '_type_') else None), (name, n)
+    assert ctypes.sizeof(ns[name]) == ctypes.sizeof(getattr(lib, name)), name
+  assert ctypes.sizeof(ns['MaskDesc']) == 48
+
+
+def test_sanitizer_build_of_the_shim():
+  """`make asan` (csrc/Makefile): the host side of the C-ABI shim under AddressSanitizer + UBSan, the launchers
+  replaced by stand-ins that check every derived workspace pointer, driven by a C program through include/mmt_attn.h
+  (SURVEY.md section 5).  CPU only."""
+  import shutil
+  import subprocess
+  if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
+    pytest.skip('no hipcc on this machine')
+  csrc = os.path.join(ROOT, 'multimodal-long-transformer-2021_amd', 'csrc')
+  res = subprocess.run(['make', '-s', '-C', csrc, 'asan'], capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+  assert 'asan driver ok' in res.stdout and 'ERROR: AddressSanitizer' not in res.stderr and 'runtime error' not in res.stderr
+
+
 def test_argument_errors_without_gpu(lib):
   L = lib.lib()
   d = lib.AttnDesc()

@@ -85,6 +85,8 @@ def test_dense_operator_backward(cfg, dtype):
     dict(B=2, S=300, N=2, R=32, radius=64, g0=250, ng=8, m=12, valid=[300, 211]),
     dict(B=1, S=256, N=1, R=32, radius=0, g0=3, ng=40, m=12),
     dict(B=1, S=200, N=2, R=49, radius=20, g0=150, ng=5, id_mode=2, m=12, P=10, r=2),
+    # a small image: the cross-modal part ids P^2 + 8 + 2m + 1 (+ 1) = 31 / 32 are BELOW R and index real table rows
+    dict(B=1, S=64, N=2, R=49, radius=8, g0=40, ng=2, id_mode=2, m=3, P=4, r=1),
     # 2-D ids with a patch row of >= 32 positions (look-up-table tiles of the lean kernels, bf16): table width 32
     # (r = 1, the reference's *_2d*.yaml) and 64 (r = 2); ragged batch; R below the text id range
     dict(B=2, S=1200, N=2, R=49, radius=64, g0=1100, ng=8, id_mode=2, m=12, P=33, r=1, valid=[1200, 1111]),
@@ -272,3 +274,32 @@ def test_listed_global_tokens_forward_backward_and_materialised_mask(dtype):
   rc = _lib.lib().mmt_attn_fwd(d, tq.data_ptr(), tk.data_ptr(), tv.data_ptr(), te.data_ptr(), tb.data_ptr(), None, None,
                                o1.data_ptr(), None, ws.data_ptr(), ws.numel(), None)
   assert rc == -2 and b'listed global-token set' in _lib.lib().mmt_last_error()      # MMT_E_UNSUPPORTED
+
+
+def test_listed_global_mask_cache_is_not_keyed_on_the_address():
+  """Two batches whose valid_len tensors land at the SAME device address (the caching allocator hands a freed block
+  back) with different lengths: the second call must build its own dense mask, not reuse the first one's (the cache
+  entry is tied to the tensor object, and dies with it)."""
+  import gc
+  import mmt_amd
+  from mmt_amd import ops
+  B, S, N, R, m = 2, 160, 1, 32, 12
+  gidx = (5, 9, 120)
+  q, k, v, emb, bias = attention_inputs(B, S, N, R, seed=41)
+  dev = lambda x: torch.from_numpy(x).cuda().contiguous()
+  tq, tk, tv, te, tb = (dev(x) for x in (q, k, v, emb, bias))
+  pat = mmt_amd.AttentionPattern(local_radius=16, id_mode=1, max_dist=m, global_index=gidx)
+  ops.clear_pattern_cache()
+  outs, ptrs = [], []
+  for valid in ([160, 100], [90, 160]):
+    vl = torch.tensor(valid, dtype=torch.int32, device='cuda')
+    ptrs.append(vl.data_ptr())
+    o, _ = mmt_amd.relative_attention_forward(tq, tk, tv, te, tb, pattern=pat, valid_len=vl)
+    mask, ids = dense_side_inputs(B, S, valid, 16, 0, 0, 1, m, gidx=gidx)
+    ref, _ = oa.relative_attention_fwd(q, k, v, emb, bias, mask, ids)
+    assert np.abs(o.cpu().numpy() - ref).max() < 1e-3, valid
+    del vl, o
+    gc.collect()
+    assert 'last' not in ops._DENSE_CACHE          # the entry went with its valid_len tensor
+  if ptrs[0] != ptrs[1]:
+    pytest.skip('results correct, but the allocator did not hand the block back: address reuse not exercised')

@@ -86,6 +86,8 @@ def test_dense_operator(cfg, dtype):
     dict(B=2, S=300, N=2, R=32, radius=64, g0=250, ng=8, m=12, valid=[300, 211]),
     dict(B=1, S=256, N=1, R=32, radius=0, g0=3, ng=40, m=12),              # radius 0, 2 global row blocks
     dict(B=1, S=200, N=2, R=49, radius=20, g0=150, ng=5, id_mode=2, m=12, P=10, r=2),
+    # a small image: the cross-modal part ids P^2 + 8 + 2m + 1 (+ 1) = 31 / 32 are BELOW R and index real table rows
+    dict(B=1, S=64, N=2, R=49, radius=8, g0=40, ng=2, id_mode=2, m=3, P=4, r=1),
     # 2-D ids with a patch row of >= 32 positions: image x image tiles go through the (dx, dy) look-up table of
     # the lean kernels (bf16); the reference's *_2d*.yaml use r = 1, m = 12, R = 49 (table width 32), r = 2 needs 64
     dict(B=2, S=1200, N=2, R=49, radius=64, g0=1100, ng=8, id_mode=2, m=12, P=33, r=1, valid=[1200, 1111]),

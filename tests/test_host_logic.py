@@ -80,6 +80,59 @@ def test_yaml_and_dotted_overrides(tmp_path):
     configs.parse_configuration('mmt/pretraining', [str(path)], strict=True)
 
 
+REF_YAMLS = '/root/reference/src/exp_yamls'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_YAMLS), reason='the reference tree is not on this machine (GPU box)')
+def test_reference_yamls_parse_in_place():
+  """Every experiment YAML the reference ships (read where it lies, never copied) loads through the registry; the
+  only keys left unknown are the ones the reference's own dataclasses lack too."""
+  import glob
+  q11 = ('use_image_text_matching_label',)
+  paths = sorted(glob.glob(os.path.join(REF_YAMLS, '*', '*', '*.yaml')))
+  assert len(paths) >= 9
+  for path in paths:
+    exp = 'mmt/pretraining' if os.sep + 'pretrain' + os.sep in path else 'mmt/classification'
+    with warnings.catch_warnings(record=True) as w:
+      warnings.simplefilter('always')
+      cfg = configs.parse_configuration(exp, [path])
+    extra = [str(x.message) for x in w if 'unknown config key' in str(x.message) and not any(k in str(x.message) for k in q11)]
+    assert not extra, (path, extra)
+    assert cfg.task.model.encoder.type == 'mmt'
+    if exp == 'mmt/classification':
+      d = cfg.task.train_data
+      assert isinstance(d, configs.MmtClassificationDataConfig) and d.negative_positive_ratio >= 1 and d.pos_weight > 0
+      assert cfg.trainer.best_checkpoint_metric_comp in ('higher', 'lower')
+  # the retrieval experiment carries the retrieval loader's fields (retrieval_dataloader.py:31-43)
+  r = configs.get_exp_config('mmt/retrieval').task.train_data
+  assert isinstance(r, configs.MmtRetrievalDataConfig)
+  assert (r.image_input_path, r.num_text_examples, r.drop_remainder, r.include_image_text_index) == ('', 0, False, True)
+  assert configs.get_exp_config('mmt/retrieval').task.validation_data.is_training is False
+
+
+def test_classification_data_config_drives_the_matching_step():
+  """`negative_positive_ratio` / `min_shift` of the data config reach the in-batch negatives
+  (classification_dataloader.py:132-140); `pos_weight` the retrieval labels (data_utils.py:744-760)."""
+  from mmt_amd import feature_pipeline as fp
+  cfg = configs.get_exp_config('mmt/classification')
+  cfg.override({'task.train_data.negative_positive_ratio': 3, 'task.train_data.min_shift': 2})
+  d = cfg.task.train_data
+  assert fp.matching_batch_size(d, 4) == (5 // 4 + 2) * 4
+  B = 12
+  feats = {'text_token_ids': torch.arange(B * 2).reshape(B, 2), 'num_text_wordpieces': torch.arange(B),
+           'patch_token_ids': torch.arange(B * 3).reshape(B, 3), 'patch_embeddings': torch.zeros(B, 3, 4),
+           'num_image_wordpieces': torch.full((B,), 5)}
+  out = fp.make_matching_features_from_config(d, feats, torch.arange(B))
+  assert out['itm_label_ids'].shape == (B * 4,) and int(out['itm_label_ids'].sum()) == B
+  assert torch.equal(out['itm_pos_weights'][:B], torch.full((B,), 3.0)) and torch.equal(out['itm_pos_weights'][B:], torch.ones(3 * B))
+  for i in range(1, 4):                                        # copy i: text rolled by min_shift + i
+    assert torch.equal(out['num_text_wordpieces'][i * B:(i + 1) * B], torch.roll(torch.arange(B), 2 + i))
+  lab = fp.make_retrieval_labels({'image_index': torch.tensor([0, 1, 2, 3]), 'gt_image_index': torch.tensor([0, 2, 2, 0])},
+                                 pos_weight=4.0)
+  assert lab['label_ids'].tolist() == [1, 0, 1, 0] and lab['label_ids'].dtype == torch.int32
+  assert lab['label_weights'].tolist() == [4.0, 1.0, 4.0, 1.0]
+
+
 def test_learning_rate_schedule_and_decay_groups():
   oc = configs.OptimizerConfig(initial_learning_rate=5e-4, decay_steps=40000, warmup_steps=4000)
   assert optimization.learning_rate_at(oc, 0) == 0.0
@@ -183,16 +236,19 @@ def test_dropout_seed_stream_depends_on_step_micro_step_and_rank():
     assert not set(a) & set(other)
 
 
-def test_gradient_reduce_mode_follows_scale_loss(monkeypatch):
+def test_gradient_reduce_mode_follows_the_task_config():
   from mmt_amd import tasks
-  class C:
-    scale_loss = True
-  assert tasks.gradient_reduce_mode(C()) == 'sum'       # pretraining.py:286-296 + SUM in apply_gradients
-  C.scale_loss = False
-  monkeypatch.delenv('MMT_REFERENCE_SUM', raising=False)
-  assert tasks.gradient_reduce_mode(C()) == 'mean'
-  monkeypatch.setenv('MMT_REFERENCE_SUM', '1')
-  assert tasks.gradient_reduce_mode(C()) == 'sum'
+  pre = configs.get_exp_config('mmt/pretraining').task
+  assert tasks.gradient_reduce_mode(pre) == 'mean'       # build default with scale_loss False
+  pre.override({'gradient_reduction': 'sum'})
+  assert tasks.gradient_reduce_mode(pre) == 'sum'        # the reference's literal SUM (pretraining.py:273)
+  pre.override({'gradient_reduction': 'mean', 'scale_loss': True})
+  assert tasks.gradient_reduce_mode(pre) == 'sum'        # pretraining.py:286-296: loss / replicas, then SUM
+  cls = configs.parse_configuration('mmt/classification', params_override='task.gradient_reduction=sum').task
+  assert tasks.gradient_reduce_mode(cls) == 'sum'
+  cls.gradient_reduction = 'median'
+  with pytest.raises(ValueError):
+    tasks.gradient_reduce_mode(cls)
 
 
 def test_attention_pattern_normalizes_listed_global_sets():
