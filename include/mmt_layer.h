@@ -232,6 +232,11 @@ int mmt_embed_bwd(const mmt_embed_desc* desc, const void* dout, const int32_t* s
  * Backward: dlogits[row, i] = (softmax(logits[row])[i] - [i == label]) * coef[row], written in `dtype`. */
 int mmt_xent_fwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld,
                  const int32_t* labels, float* loss, float* lse, void* stream);
+/* The same pass also reporting argmax[row] = the FIRST index of the row's largest logit -- what tf.argmax, hence
+ * tf.keras.metrics.SparseCategoricalAccuracy (src/tasks/pretraining.py:183-222), compares with the label -- so that the
+ * accuracy metrics cost no second sweep over the 30522-way logits.  `argmax` may be NULL. */
+int mmt_xent_fwd_argmax(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld,
+                        const int32_t* labels, float* loss, float* lse, int32_t* argmax, void* stream);
 int mmt_xent_bwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld,
                  const int32_t* labels, const float* lse, const float* coef, void* dlogits, int64_t ldd,
                  void* stream);

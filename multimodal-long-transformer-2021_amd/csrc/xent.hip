@@ -16,13 +16,15 @@ template <typename T> __device__ __forceinline__ float ldval(const T* p, long i)
 
 struct OnlineLse {
   float m = -INFINITY, s = 0.f;
-  __device__ __forceinline__ void add(float x) {
-    if (x > m) { s = s * __expf(m - x) + 1.f; m = x; }
+  int am = 0x7fffffff;          // index of the FIRST element equal to m (tf.argmax / SparseCategoricalAccuracy's tie rule)
+  __device__ __forceinline__ void add(float x, int i) {
+    if (x > m) { s = s * __expf(m - x) + 1.f; m = x; am = i; }       // a thread meets its indices in ascending order
     else s += __expf(x - m);
   }
-  __device__ __forceinline__ void merge(float m2, float s2) {
+  __device__ __forceinline__ void merge(float m2, float s2, int am2) {
     const float mm = fmaxf(m, m2);
     if (mm == -INFINITY) return;
+    am = m2 > m ? am2 : (m2 == m ? min(am, am2) : am);
     s = s * __expf(m - mm) + s2 * __expf(m2 - mm);
     m = mm;
   }
@@ -31,8 +33,9 @@ struct OnlineLse {
 // rows x C logits (row stride ld elements) -> loss[row] = lse - logits[label], lse[row] (natural log)
 template <typename T>
 __global__ __launch_bounds__(256) void xent_fwd_kernel(const T* logits, long ld, int C, const int* labels,
-                                                       float* loss, float* lse_out) {
+                                                       float* loss, float* lse_out, int* amax_out) {
   __shared__ float rm[4], rs[4];
+  __shared__ int ra[4];
   const long row = blockIdx.x;
   const T* x = logits + row * ld;
   OnlineLse acc;
@@ -42,21 +45,25 @@ __global__ __launch_bounds__(256) void xent_fwd_kernel(const T* logits, long ld,
     const uint32_t* xp = reinterpret_cast<const uint32_t*>(x);
     for (int i = threadIdx.x; i < np; i += 256) {
       const uint32_t w = xp[i];
-      acc.add(__uint_as_float(w << 16));
-      acc.add(__uint_as_float(w & 0xFFFF0000u));
+      acc.add(__uint_as_float(w << 16), 2 * i);
+      acc.add(__uint_as_float(w & 0xFFFF0000u), 2 * i + 1);
     }
-    if ((C & 1) && threadIdx.x == 0) acc.add(ldval(x, C - 1));
+    if (C & 1) {                      // the odd last element: folded in by thread 0 through a merge (its own indices
+      OnlineLse tail;                 // would no longer be ascending)
+      if (threadIdx.x == 0) { tail.add(ldval(x, C - 1), C - 1); acc.merge(tail.m, tail.s, tail.am); }
+    }
   } else {
-    for (int i = threadIdx.x; i < C; i += 256) acc.add(ldval(x, i));
+    for (int i = threadIdx.x; i < C; i += 256) acc.add(ldval(x, i), i);
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc.merge(__shfl_xor(acc.m, o, 64), __shfl_xor(acc.s, o, 64));
+  for (int o = 32; o > 0; o >>= 1) acc.merge(__shfl_xor(acc.m, o, 64), __shfl_xor(acc.s, o, 64), __shfl_xor(acc.am, o, 64));
   const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { rm[wave] = acc.m; rs[wave] = acc.s; }
+  if ((threadIdx.x & 63) == 0) { rm[wave] = acc.m; rs[wave] = acc.s; ra[wave] = acc.am; }
   __syncthreads();
   if (threadIdx.x == 0) {
     OnlineLse t;
-    for (int w = 0; w < 4; ++w) t.merge(rm[w], rs[w]);
+    for (int w = 0; w < 4; ++w) t.merge(rm[w], rs[w], ra[w]);
+    if (amax_out) amax_out[row] = t.am;
     const float lse = t.m + logf(t.s);
     const int lab = labels[row];
     lse_out[row] = lse;
@@ -128,12 +135,17 @@ int mmt_weighted_loss(int64_t rows, const float* loss, const float* weight, cons
 
 int mmt_xent_fwd(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld, const int32_t* labels,
                  float* loss, float* lse, void* stream) {
+  return mmt_xent_fwd_argmax(rows, C, dtype, logits, ld, labels, loss, lse, nullptr, stream);
+}
+
+int mmt_xent_fwd_argmax(int64_t rows, int32_t C, int32_t dtype, const void* logits, int64_t ld, const int32_t* labels,
+                        float* loss, float* lse, int32_t* argmax, void* stream) {
   if (!logits || !labels || !loss || !lse) return mmt::fail(MMT_E_INVALID, "mmt_xent_fwd: NULL argument");
   if (rows <= 0 || C <= 0 || ld < C) return mmt::fail(MMT_E_INVALID, "mmt_xent_fwd: bad shape");
   if (dtype != MMT_F32 && dtype != MMT_BF16) return mmt::fail(MMT_E_INVALID, "mmt_xent_fwd: bad dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == MMT_BF16) hipLaunchKernelGGL(mmt::xent_fwd_kernel<__bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const __bf16*)logits, (long)ld, C, labels, loss, lse);
-  else hipLaunchKernelGGL(mmt::xent_fwd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, (long)ld, C, labels, loss, lse);
+  if (dtype == MMT_BF16) hipLaunchKernelGGL(mmt::xent_fwd_kernel<__bf16>, dim3((unsigned)rows), dim3(256), 0, st, (const __bf16*)logits, (long)ld, C, labels, loss, lse, argmax);
+  else hipLaunchKernelGGL(mmt::xent_fwd_kernel<float>, dim3((unsigned)rows), dim3(256), 0, st, (const float*)logits, (long)ld, C, labels, loss, lse, argmax);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_xent_fwd: %s", hipGetErrorString(e));
 }

@@ -25,7 +25,7 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_workspace_bytes', 'mmt_attn
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
            'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_colsum_reduce', 'mmt_accumulate_grad', 'mmt_grad_clip_scale', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
            'mmt_wgrad_bias_accumulate', 'mmt_wgrad_grouped', 'mmt_wgrad_group_workspace_bytes', 'mmt_wgrad_workspace_bytes', 'mmt_wgrad_set_cu_budget', 'mmt_embed_fwd', 'mmt_embed_bwd',
-           'mmt_embed_workspace_bytes', 'mmt_xent_fwd', 'mmt_xent_bwd', 'mmt_xent_bwd_scaled', 'mmt_weighted_loss', 'mmt_colsum', 'mmt_colsum_workspace_bytes', 'mmt_ln_bwd_add', 'mmt_ffn_gelu_gemm', 'mmt_ffn_dgelu_gemm', 'mmt_ffn_set_cu_budget')
+           'mmt_embed_workspace_bytes', 'mmt_xent_fwd', 'mmt_xent_fwd_argmax', 'mmt_xent_bwd', 'mmt_xent_bwd_scaled', 'mmt_weighted_loss', 'mmt_colsum', 'mmt_colsum_workspace_bytes', 'mmt_ln_bwd_add', 'mmt_ffn_gelu_gemm', 'mmt_ffn_dgelu_gemm', 'mmt_ffn_set_cu_budget')
 
 
 class EmbedDesc(ctypes.Structure):
@@ -154,6 +154,8 @@ def lib() -> ctypes.CDLL:
   L.mmt_embed_bwd.argtypes = [ed] + [vp] * 12 + [ctypes.c_size_t, vp]
   L.mmt_embed_workspace_bytes.restype = ctypes.c_size_t
   L.mmt_embed_workspace_bytes.argtypes = [ed]
+  L.mmt_xent_fwd_argmax.restype = ctypes.c_int
+  L.mmt_xent_fwd_argmax.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int64, vp, vp, vp, vp, vp]
   L.mmt_xent_fwd.restype = ctypes.c_int
   L.mmt_xent_fwd.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, vp, ctypes.c_int64, vp, vp, vp, vp]
   L.mmt_colsum_workspace_bytes.restype = ctypes.c_size_t

@@ -822,7 +822,7 @@ class _WeightedXentFn(torch.autograd.Function):
   per loss term (`pretraining.py:95-140`)."""
 
   @staticmethod
-  def forward(ctx, logits, labels, weight, lmul, mask, mask_div):
+  def forward(ctx, logits, labels, weight, lmul, mask, mask_div, want_argmax=False):
     rows, C = logits.shape
     dev = logits.device
     lab = labels.reshape(-1).to(torch.int32).contiguous()
@@ -831,17 +831,21 @@ class _WeightedXentFn(torch.autograd.Function):
     mk = None if mask is None else mask.reshape(-1).to(torch.float32).contiguous()
     buf = torch.empty(3 * rows + 3, dtype=torch.float32, device=dev)      # loss | lse | coef | {loss, num, den}
     loss, lse, coef, out3 = buf[:rows], buf[rows:2 * rows], buf[2 * rows:3 * rows], buf[3 * rows:]
+    amax = torch.empty(rows, dtype=torch.int32, device=dev) if want_argmax else None
     with torch.cuda.device(dev):
-      _lib.check(_lib.lib().mmt_xent_fwd(rows, C, _dtype_code(logits.dtype), _p(logits), logits.stride(0), _p(lab),
-                                         _p(loss), _p(lse), _stream(logits)))
+      _lib.check(_lib.lib().mmt_xent_fwd_argmax(rows, C, _dtype_code(logits.dtype), _p(logits), logits.stride(0), _p(lab),
+                                                _p(loss), _p(lse), _p(amax) if want_argmax else None, _stream(logits)))
       _lib.check(_lib.lib().mmt_weighted_loss(rows, _p(loss), _p(w), _p(lm) if lm is not None else None,
                                               _p(mk) if mk is not None else None, int(mask_div), _p(out3), _p(coef),
                                               _stream(logits)))
     ctx.save_for_backward(logits, lab, buf)
+    if want_argmax:
+      ctx.mark_non_differentiable(amax)
+      return out3[0], amax
     return out3[0]
 
   @staticmethod
-  def backward(ctx, dloss):
+  def backward(ctx, dloss, *_unused):
     logits, lab, buf = ctx.saved_tensors
     rows, C = logits.shape
     lse, coef = buf[rows:2 * rows], buf[2 * rows:3 * rows]
@@ -850,16 +854,18 @@ class _WeightedXentFn(torch.autograd.Function):
     with torch.cuda.device(logits.device):
       _lib.check(_lib.lib().mmt_xent_bwd_scaled(rows, C, _dtype_code(logits.dtype), _p(logits), logits.stride(0), _p(lab),
                                                 _p(lse), _p(coef), _p(g), _p(dlogits), dlogits.stride(0), _stream(logits)))
-    return dlogits, None, None, None, None, None
+    return dlogits, None, None, None, None, None, None
 
 
-def weighted_softmax_cross_entropy(logits, labels, weight, lmul=None, mask=None, mask_div=1):
+def weighted_softmax_cross_entropy(logits, labels, weight, lmul=None, mask=None, mask_div=1, return_argmax=False):
   """Scalar `divide_no_nan(sum w l, sum w)` over the rows of 2-D `logits` (fp32 | bf16, unit column stride, at most
-  65535 rows); `mask` (one value per `mask_div` consecutive rows) multiplies the weights, `lmul` the row losses."""
+  65535 rows); `mask` (one value per `mask_div` consecutive rows) multiplies the weights, `lmul` the row losses.
+  `return_argmax`: also the int32 [rows] first-occurrence arg-max of every row, taken in the same pass over the
+  logits (for the accuracy metrics of `process_metrics`, src/tasks/pretraining.py:198-222)."""
   if logits.dim() != 2 or logits.stride(1) != 1 or not 0 < logits.shape[0] <= 65535:
     raise ValueError('weighted_softmax_cross_entropy expects [0 < rows <= 65535, C] logits with unit column stride')
   _check(logits, labels)
-  return _WeightedXentFn.apply(logits, labels, weight, lmul, mask, mask_div)
+  return _WeightedXentFn.apply(logits, labels, weight, lmul, mask, mask_div, bool(return_argmax))
 
 
 def softmax_cross_entropy(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:

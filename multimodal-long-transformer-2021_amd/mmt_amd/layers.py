@@ -622,17 +622,24 @@ class ClassificationHead(nn.Module):
 
 
 def weighted_sparse_categorical_crossentropy_loss(logits, labels, label_weights, metrics=None,
-                                                  name='', pos_weights=None, example_mask=None):
+                                                  name='', pos_weights=None, example_mask=None, aux=None):
   """`src/modeling/losses/weighted_sparse_categorical_crossentropy_loss.py:17-43` incl.
   `divide_no_nan` (an all-zero weight vector gives loss 0, App. B q13).  `example_mask` ([B], optional) multiplies
-  the weights of every row of its example (the ITM label that masks the MLM / MPP terms, `pretraining.py:101-109`)."""
+  the weights of every row of its example (the ITM label that masks the MLM / MPP terms, `pretraining.py:101-109`).
+  `metrics`: the task's metric objects (list, as the reference passes them; `{name}_loss` is updated, `:42`) or the
+  legacy dict that collects the loss values.  `aux` (dict, optional): receives `{name}_argmax`, the first-occurrence
+  arg-max of every logits row from the loss kernel's own pass, for `process_metrics`."""
+  from . import metrics as metrics_lib
   flat = logits.reshape(-1, logits.shape[-1])
+  want_amax = aux is not None and f'{name}_accuracy' in metrics_lib.by_name(metrics)
   if flat.is_cuda and flat.dtype in (torch.float32, torch.bfloat16) and flat.stride(1) == 1 and 0 < flat.shape[0] <= 65535:
     # per-row losses in one HIP pass over the logits in their storage dtype, then sums + guarded division +
     # per-row derivative in one more launch
     div = flat.shape[0] // example_mask.numel() if example_mask is not None else 1
     loss = fused.weighted_softmax_cross_entropy(flat, labels.reshape(-1), label_weights, lmul=pos_weights,
-                                                mask=example_mask, mask_div=div)
+                                                mask=example_mask, mask_div=div, return_argmax=want_amax)
+    if want_amax:
+      loss, aux[f'{name}_argmax'] = loss[0], loss[1].view(labels.shape)
   else:
     unweighted = F.cross_entropy(flat.float(), labels.reshape(-1).long(), reduction='none').view(labels.shape)
     if pos_weights is not None:
@@ -644,5 +651,9 @@ def weighted_sparse_categorical_crossentropy_loss(logits, labels, label_weights,
     loss = torch.where(den != 0, num / torch.where(den != 0, den, torch.ones_like(den)),
                        torch.zeros_like(num))
   if metrics is not None:
-    metrics.setdefault(f'{name}_loss', []).append(loss.detach())
+    named = metrics_lib.by_name(metrics)
+    if f'{name}_loss' in named:
+      named[f'{name}_loss'].update_state(loss.detach())
+    elif isinstance(metrics, dict):
+      metrics.setdefault(f'{name}_loss', []).append(loss.detach())
   return loss

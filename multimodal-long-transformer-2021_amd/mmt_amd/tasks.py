@@ -115,6 +115,8 @@ class _TaskBase:
       small_labels = {k: v[sl] for k, v in labels.items()}
       outputs = model(**small_inputs, training=True)
       loss = self.build_losses(small_labels, outputs, metrics)
+      if metrics:                        # pretraining.py:297 / classification.py:211 (after the gradient in the reference;
+        self.process_metrics(metrics, small_labels, outputs)      # nothing here depends on that order)
       if self.task_config.scale_loss:   # pretraining.py:286-296: gradient of loss / replicas
         grad_loss = loss / self.num_replicas
       else:
@@ -149,9 +151,16 @@ class _TaskBase:
     return checkpoint.restore_items(path, checkpoint.model_items(model))
 
   def validation_step(self, inputs, model, metrics=None):
+    """`pretraining.py:300-313` / `classification.py:214-227`: forward, losses, metrics."""
     inputs, labels = inputs
     outputs = model(**inputs, training=False)
-    return {self.loss: self.build_losses(labels, outputs, metrics)}
+    loss = self.build_losses(labels, outputs, metrics)
+    if metrics:
+      self.process_metrics(metrics, labels, outputs)
+    return {self.loss: loss}
+
+  def process_metrics(self, metrics, labels, model_outputs):
+    del metrics, labels, model_outputs
 
 
 @register_task_cls(configs.PretrainingTaskConfig)
@@ -171,18 +180,50 @@ class PretrainingTask(_TaskBase):
         mpp_activation=config.mpp_activation, mpp_initializer=config.mpp_initializer,
         classification_heads=heads, bind_word_embedding_table=config.bind_word_embedding_table)
 
+  def build_metrics(self, training=None):
+    """`pretraining.py:183-196`: accuracy + mean loss for MLM, MPP and every classification head."""
+    del training
+    from . import metrics as M
+    out = [M.SparseCategoricalAccuracy('mlm_accuracy'), M.Mean('mlm_loss'),
+           M.SparseCategoricalAccuracy('mpp_accuracy'), M.Mean('mpp_loss')]
+    for cfg in self.task_config.model.cls_heads:
+      out += [M.SparseCategoricalAccuracy(f'{cfg.name}_accuracy'), M.Mean(f'{cfg.name}_loss')]
+    return out
+
+  def process_metrics(self, metrics, labels, model_outputs):
+    """`pretraining.py:198-222`: the accuracies, MLM / MPP weights masked by the example's ITM label.  The arg-max
+    of each logits row comes from the loss kernel's pass when `build_losses` left it in `model_outputs`."""
+    from . import metrics as M
+    named = M.by_name(metrics)
+    if not named:
+      return
+    if 'itm_label_weights' in labels:
+      itm = labels['itm_label_ids'].to(torch.float32).unsqueeze(1)
+      mlm_w, mpp_w = labels['mlm_label_weights'] * itm, labels['mpp_label_weights'] * itm
+    else:
+      mlm_w, mpp_w = labels['mlm_label_weights'], labels['mpp_label_weights']
+    if 'mlm_accuracy' in named:
+      named['mlm_accuracy'].update_state(labels['mlm_label_ids'], model_outputs['mlm_logits'], mlm_w,
+                                         argmax=model_outputs.get('mlm_argmax'))
+    if 'mpp_accuracy' in named:
+      named['mpp_accuracy'].update_state(labels['mpp_label_ids'], model_outputs['mpp_logits'], mpp_w,
+                                         argmax=model_outputs.get('mpp_argmax'))
+    if 'itm_accuracy' in named and 'itm_logits' in model_outputs:
+      named['itm_accuracy'].update_state(labels['itm_label_ids'], model_outputs['itm_logits'],
+                                         labels['itm_label_weights'], argmax=model_outputs.get('itm_argmax'))
+
   def build_losses(self, labels, model_outputs, metrics=None, aux_losses=None):
     """`pretraining.py:95-140`."""
     wsce = layers.weighted_sparse_categorical_crossentropy_loss
     # MLM / MPP losses are masked on negative pairs: the example's ITM label multiplies its rows' weights
     itm = labels['itm_label_ids'].float() if 'itm_label_weights' in labels else None
     total = wsce(model_outputs['mlm_logits'], labels['mlm_label_ids'], labels['mlm_label_weights'], metrics, 'mlm',
-                 example_mask=itm)
+                 example_mask=itm, aux=model_outputs)
     total = total + wsce(model_outputs['mpp_logits'], labels['mpp_label_ids'], labels['mpp_label_weights'], metrics,
-                         'mpp', example_mask=itm)
+                         'mpp', example_mask=itm, aux=model_outputs)
     if 'itm_label_weights' in labels:
       total = total + wsce(model_outputs['itm_logits'], labels['itm_label_ids'],
-                           labels['itm_label_weights'], metrics, 'itm')
+                           labels['itm_label_weights'], metrics, 'itm', aux=model_outputs)
     if aux_losses:
       total = total + sum(aux_losses)
     return total
@@ -228,11 +269,50 @@ class ClassificationTask(_TaskBase):
           mapping[key] = item
     return checkpoint.restore_items(path, mapping)
 
+  def _logits_key(self, model_outputs):
+    if self.logits_field in model_outputs:
+      return self.logits_field
+    return next(k for k in model_outputs if k.endswith('_logits'))      # e.g. head named 'itm' -> 'itm_logits'
+
+  def build_metrics(self, training=None):
+    """`classification.py:132-148`: AUC(PR) for one class, accuracy + AUC(PR) for two, accuracy beyond; plus the
+    mean of the task's loss."""
+    del training
+    from . import metrics as M
+    n = self.task_config.model.num_classes
+    if n == 1:
+      out = [M.AUC('auc', curve='PR')]
+    elif n == 2:
+      out = [M.SparseCategoricalAccuracy('cls_accuracy'), M.AUC('auc', curve='PR')]
+    else:
+      out = [M.SparseCategoricalAccuracy('cls_accuracy')]
+    out.append(M.Mean(f'{self.task_name}_loss'))
+    return out
+
+  def process_metrics(self, metrics, labels, model_outputs):
+    """`classification.py:150-170`."""
+    from . import metrics as M
+    named = M.by_name(metrics)
+    if not named:
+      return
+    label_ids, label_weights = labels[self.label_field], labels[self.label_weights_field]
+    logits = model_outputs[self._logits_key(model_outputs)]
+    if 'auc' in named:
+      n = self.task_config.model.num_classes
+      if n == 1:
+        probs = torch.sigmoid(logits.float().reshape(-1))
+      elif n == 2:
+        probs = torch.softmax(logits.float(), dim=-1)[:, 1]          # the probability of True
+      else:
+        raise ValueError('auc requires # classes either 1 or 2.')
+      named['auc'].update_state(label_ids, probs, label_weights)
+    if 'cls_accuracy' in named:
+      named['cls_accuracy'].update_state(label_ids, logits, label_weights,
+                                         argmax=model_outputs.get(f'{self.task_name}_argmax'))
+
   def build_losses(self, labels, model_outputs, metrics=None, aux_losses=None):
     """`classification.py:100-126` (the num_classes == 1 branch is dead in the reference, q6)."""
-    logits_key = self.logits_field
-    if logits_key not in model_outputs:      # e.g. head named 'itm' -> 'itm_logits'
-      logits_key = next(k for k in model_outputs if k.endswith('_logits'))
+    logits_key = self._logits_key(model_outputs)
     loss = layers.weighted_sparse_categorical_crossentropy_loss(
         model_outputs[logits_key], labels[self.label_field], labels[self.label_weights_field],
         metrics, self.task_name, pos_weights=labels.get(self.pos_weights_field))

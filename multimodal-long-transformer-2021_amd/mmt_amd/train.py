@@ -52,15 +52,21 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
     if strategy.rank == 0 and model_dir:
       checkpoint.save(model_dir, step, model, optimizer, max_to_keep=params.trainer.max_to_keep)
 
+  from . import metrics as metrics_lib
   if 'train' in mode:
     t0 = time.perf_counter()
+    # `task.build_metrics()` objects, updated on the device inside every step (process_metrics, pretraining.py:297);
+    # read -- one all-reduce + one host copy each -- only on logging steps, then reset like orbit's summary loop
+    train_metrics = task.build_metrics(training=True)
     for step in range(start, steps):
       optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, step))
-      out = task.train_step(next(data), model, optimizer, metrics={}, reducer=reducer,
+      out = task.train_step(next(data), model, optimizer, metrics=train_metrics, reducer=reducer,
                             clip_norm=opt_cfg.gradient_clip_norm, step=step + 1)
       if step % log_every == 0 or step == steps - 1:
         loss = float(out[task.loss])
-        logs.append({'step': step, 'loss': loss, 'elapsed_s': time.perf_counter() - t0})
+        logs.append({'step': step, 'loss': loss, 'elapsed_s': time.perf_counter() - t0,
+                     **{k: round(v, 6) for k, v in metrics_lib.results(train_metrics).items()}})
+        metrics_lib.reset(train_metrics)
         if strategy.rank == 0:
           print(json.dumps(logs[-1]), flush=True)
       if ckpt_every and (step + 1) % ckpt_every == 0 and step + 1 < steps:
@@ -69,8 +75,10 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
       save(steps)
   if 'eval' in mode:
     vdata = task.build_inputs(params.task.validation_data, device=device, rank=strategy.rank)
-    out = task.validation_step(next(vdata), model, metrics={})
-    logs.append({'validation_loss': float(out[task.loss])})
+    eval_metrics = task.build_metrics(training=False)
+    out = task.validation_step(next(vdata), model, metrics=eval_metrics)
+    logs.append({'validation_loss': float(out[task.loss]),
+                 **{f'validation_{k}': round(v, 6) for k, v in metrics_lib.results(eval_metrics).items()}})
     if strategy.rank == 0:
       print(json.dumps(logs[-1]), flush=True)
   return model, logs
