@@ -79,6 +79,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   unsigned char* vlds = xlds + L::kTile;
   int* lut = reinterpret_cast<int*>(smem + kEImg + 4 * kWave);        // REL == 2: one per workgroup
 
+#ifdef MMT_STAMP
+  long long* dbg = (p.dbg && (p.dbg_mode & 1) == 0 && blockIdx.x == 900) ? p.dbg + wave * 32 : nullptr;
+#define QSTAMP(i) do { if (dbg && lane == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QSTAMP(i) do { } while (0)
+#endif
+  QSTAMP(0);
   const int n_tiles = (p.S + 31) >> 5, nqb = (p.S + 127) >> 7;
   const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
   // long (global-row) items first, then the band blocks with the XCD remap: measured 8 % faster
@@ -145,11 +152,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     for (int u = 0; u < 4; ++u) kt[u] = buf16(rk, voff_kc, (k0 + 8 * u) * ks1b);
 #pragma unroll
     for (int u = 0; u < 4; ++u) vt[u] = buf16(rv, voff_vc, (k0 + 8 * u) * vs1b);
+    QSTAMP(1);
     if (HAS_REL) {           // every wave of the workgroup takes part (the plane, hence E, is the same for all four)
       stage_e_image<Rp, REL>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
       if (REL == 2) build_lut2d<Rp>(lut, p.pat, p.R, threadIdx.x, 256);
       __syncthreads();
     }
+    QSTAMP(2);
     if (!live) return;
     float acc = 0.f;
 #pragma unroll
@@ -196,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   }
   wave_lds_sync();
 
+  QSTAMP(3);
   f32x16 a0 = {0}, a1 = {0};
   float far_neg_acc = 0.f, far_pos_acc = 0.f;
   const float* trow = tab + r * kTStride(Rp);
@@ -371,7 +381,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     }
     mma_xt(a0, a1, VTile<T>{}, xlds, ds, lane);   // dQ^T += K^T . dS^T   (gscale in the epilogue)
     wave_lds_sync();
+    QSTAMP(4 + min(it, 7));
   }
+  QSTAMP(12);
 #pragma unroll
   for (int i = 0; i < 16; ++i) { a0[i] *= p.gscale; a1[i] *= p.gscale; }
   if (REL == 1) {
@@ -425,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
       *reinterpret_cast<bf16x4*>(DQ + 32 + d) = y;
     }
   }
+  QSTAMP(13);
   if (!HAS_REL) return;
 
   // (2) the workgroup's share of dE^T[d x id] = Q^T . dRel and dbias[id] (one partial per workgroup for the
@@ -468,7 +481,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     }
     if (h == 0) reinterpret_cast<float*>(wl + kParkBias)[id] = bsum;
   }
+  QSTAMP(14);
   __syncthreads();                 // waves past the end of the sequence have exited and are not waited for
+  QSTAMP(15);
   {
     const int q0_wg = q0 - 32 * wave;
     float* pe = p.part_red + (long)band_wg * (Rp * 64 + Rp);
@@ -494,6 +509,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
       }
     }
   }
+  QSTAMP(16);
 }
 
 // =========================================================================================
@@ -530,6 +546,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       return;
     }
   }
+#ifdef MMT_STAMP
+  long long* dbg = (p.dbg && (p.dbg_mode & 1) == 1 && blockIdx.x == 900) ? p.dbg + wave * 32 : nullptr;
+#define KSTAMP(i) do { if (dbg && lane == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define KSTAMP(i) do { } while (0)
+#endif
+  KSTAMP(0);
   const int n_tiles = (p.S + 31) >> 5, nkb = (p.S + 127) >> 7;
   const int per_bn = (p.n_chunks * p.n_gblk + 3) >> 2;
   int bn, k0, chunk = 0, gblk = 0, blk;
@@ -588,11 +611,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       dot[u] = buf16(rdo, voff_oc, (q0 + 8 * u) * os1b);
     }
   }
+  KSTAMP(1);
   if (HAS_REL) {           // E image after the item's loads are in flight (see the dQ kernel)
     stage_e_image<Rp, REL>(elds, p.emb, n, p.N, p.R, p.pat.m, threadIdx.x);
     if (REL == 2) build_lut2d<Rp>(lut, p.pat, p.R, threadIdx.x, 256);
     __syncthreads();
   }
+  KSTAMP(2);
   if (!live) return;
   if (HAS_REL) {
     if (lane < Rp) {
@@ -784,7 +809,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
     mma_xt(dv0, dv1, VTile<T>{}, dolds, pr, lane);   // dV^T[d x key] += dO^T[d x q] . P[q x key]
     mma_xt(dk0, dk1, VTile<T>{}, qlds, g, lane);     // dK^T[d x key] += Q^T[d x q] . dS[q x key]
     wave_lds_sync();
+    KSTAMP(4 + min(it, 7));
   }
+  KSTAMP(12);
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk0[i] *= p.gscale; dk1[i] *= p.gscale; }
 
@@ -816,6 +843,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
     *reinterpret_cast<bf16x4*>(DK + d) = x; *reinterpret_cast<bf16x4*>(DK + 32 + d) = y;
     *reinterpret_cast<bf16x4*>(DV + d) = z; *reinterpret_cast<bf16x4*>(DV + 32 + d) = u;
   }
+  KSTAMP(13);
 }
 
 // ------------------------------------ launcher --------------------------------------------

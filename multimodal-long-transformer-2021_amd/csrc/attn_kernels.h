@@ -75,6 +75,8 @@ struct BwdParams {
   float* part_dkv;   // [B*N, n_gblk, n_chunks, 2, 32, 64] global-key partials
   float* part_red;   // [B*N * ceil(S/128) * 4 waves, Rp*64 + Rp]  per-wave dE^T / dbias partials
   int n_band_blocks, n_chunks, chunk_tiles, n_gblk, n_split;
+  long long* dbg;    // -DMMT_STAMP diagnostic builds only (see FwdParams)
+  int dbg_mode;
 };
 
 hipError_t launch_attn_bwd(const BwdParams& p, int mode, bool bf16, hipStream_t st);

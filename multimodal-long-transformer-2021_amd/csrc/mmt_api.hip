@@ -283,6 +283,10 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     (void)hipMemsetAsync(drel_emb + (size_t)p.Rp * p.N * 64, 0, (size_t)(p.R - p.Rp) * p.N * 64 * sizeof(float), st);
     if (p.drel_bias) (void)hipMemsetAsync(p.drel_bias + (size_t)p.Rp * p.N, 0, (size_t)(p.R - p.Rp) * p.N * sizeof(float), st);
   }
+#ifdef MMT_STAMP
+  if (const char* v = std::getenv("MMT_DBG_PTR")) p.dbg = reinterpret_cast<long long*>(std::strtoull(v, nullptr, 0));
+  if (const char* v = std::getenv("MMT_DBG_MODE")) p.dbg_mode = std::atoi(v);
+#endif
   hipError_t e = mmt::launch_attn_bwd(p, dense ? mmt::kDense : mmt::kBand, desc->dtype == MMT_BF16, st);
   if (e != hipSuccess) return fail(MMT_E_LAUNCH, "backward launch: %s", hipGetErrorString(e));
   return MMT_OK;
