@@ -98,6 +98,7 @@ def cpu_baseline_attention(cfg, seed=1234, budget_s=10.0, backward=False):
   dt = time.perf_counter() - t0
   what = 'forward + backward' if backward else 'forward'
   return {'value': n / dt, 'unit': f'attention-layer {"fwd+bwd" if backward else "fwd"} samples/s', 'cores': cores,
+          'host_cores_visible': os.cpu_count(),    # the box's logical CPUs; `cores` = threads used (capped at 16, the one-GPU share)
           'kind': 'port',
           'sample': f'{n} x (1 sequence x 1 attention layer {what}, S={S}, {N} heads, dense int32 '
                     f'mask+ids as the reference feeds them), numpy/BLAS restatement of the TF2 CPU '
@@ -164,7 +165,7 @@ def cpu_baseline_train_step(budget_s=10.0):
     if time.perf_counter() - t0 > budget_s:
       break
   dt = time.perf_counter() - t0
-  return {'value': n * Bm / dt, 'unit': 'train-step (fwd+loss+bwd) samples/s', 'cores': cores, 'kind': 'port',
+  return {'value': n * Bm / dt, 'unit': 'train-step (fwd+loss+bwd) samples/s', 'cores': cores, 'host_cores_visible': os.cpu_count(), 'kind': 'port',
           'sample': f'{n} micro-batches of {Bm} sequences, BASELINE config 1 (2 layers, hidden 128, 2 heads, S=256, '
                     f'dense segmented mask + 1-D ids, fp32), dense torch-CPU restatement of MmtPretrainingModel + '
                     f'build_losses with autograd (TF unavailable offline), {dt:.1f} s on {cores} threads'}
@@ -349,26 +350,34 @@ def main():
   bwd_ms = timed(attn_bwd, iters=30)
 
   traffic = traffic_bwd = traffic_commit = None   # HBM bytes per launch from the committed PMC passes
+  us_prof = us_prof_bwd = None                    # rocprofv3 kernel durations of the same workload (profiles/, same commit)
   try:
     with open(os.path.join(ROOT, 'profiles', 'attn_traffic.json')) as f:
       tj = json.load(f)
     traffic, traffic_bwd, traffic_commit = tj['fwd_hbm_bytes_per_launch'], tj['bwd_hbm_bytes_per_launch'], tj.get('commit')
+    us_prof, us_prof_bwd = tj.get('fwd_kernel_us_rocprof'), tj.get('bwd_kernel_us_rocprof')
   except (OSError, KeyError, ValueError):
     pass
 
-  def roof(ms, nbytes, nflops, traffic, kernel):
+  def roof(ms, nbytes, nflops, traffic, kernel, us_rocprof=None):
     gbs = nbytes * B / (ms * 1e-3) / 1e9
     tfs = nflops * B / (ms * 1e-3) / 1e12
     return {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_measured_at': traffic_commit,
             'kernel': kernel, 'launch_us': round(ms * 1e3, 2), 'algorithmic_bytes_per_launch': nbytes * B,
             'mfma_tflops': round(tfs, 2), 'mfma_frac': round(tfs / MFMA_BF16_PEAK_TF, 5),
-            'dropout_p': drop['dropout_p']}
+            'dropout_p': drop['dropout_p'],
+            # per-kernel average durations under rocprofv3 --kernel-trace --stats (profiles/r03_attn_kernel_stats.csv):
+            # frac can be recomputed from them as algorithmic_bytes_per_launch / sum(us) / peak
+            'kernel_us_rocprof': us_rocprof,
+            'frac_rocprof': (round(nbytes * B / (sum(us_rocprof.values()) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+                             if us_rocprof else None)}
 
   roofline = roof(attn_ms, byts, flops, traffic,
-                  'one attention-forward call, B=4 (mmt_attn_fwd: band + global-key tiles + global-row chunks + combine)')
+                  'one attention-forward call, B=4 (mmt_attn_fwd: ONE launch -- window kernel: band blocks with a shared '
+                  'K/V window, peeled global keys, flipped global-row workgroups)', us_prof)
   roofline_bwd = roof(bwd_ms, bwd_byts, 2.5 * flops, traffic_bwd,
-                      'one attention-backward call, B=4 (mmt_attn_bwd: dQ pass + dK/dV pass + table-gradient reduce)')
+                      'one attention-backward call, B=4 (mmt_attn_bwd: dQ pass + dK/dV pass + table-gradient reduce)', us_prof_bwd)
 
   if rank == 0:
     cpu = cpu_fb = cpu_step = None

@@ -283,6 +283,7 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     (void)hipMemsetAsync(drel_emb + (size_t)p.Rp * p.N * 64, 0, (size_t)(p.R - p.Rp) * p.N * 64 * sizeof(float), st);
     if (p.drel_bias) (void)hipMemsetAsync(p.drel_bias + (size_t)p.Rp * p.N, 0, (size_t)(p.R - p.Rp) * p.N * sizeof(float), st);
   }
+  if (const char* v = std::getenv("MMT_DQ_PLANE_MAJOR")) p.dq_plane_major = std::atoi(v);
 #ifdef MMT_STAMP
   if (const char* v = std::getenv("MMT_DBG_PTR")) p.dbg = reinterpret_cast<long long*>(std::strtoull(v, nullptr, 0));
   if (const char* v = std::getenv("MMT_DBG_MODE")) p.dbg_mode = std::atoi(v);

@@ -17,6 +17,15 @@ hbm = lambda ks: int(sum((2 * f[k] + w.get(k, 0.0)) * 1024 for k in ks))
 fwd_k, bwd_k = [k for k in f if is_fwd(k)], [k for k in f if not is_fwd(k)]
 cfg = bench.config3()
 _, fb, bb = bench.attn_algorithmic(cfg, 2)
+# kernel durations of the same workload under rocprofv3 --kernel-trace --stats (the third pass listed in
+# tools/attn_pmc_workload.py): average us per launch, by kernel
+ks = {}
+try:
+  for r in csv.DictReader(open('gpurun_out/attn_ks/a_kernel_stats.csv')):
+    if 'attn' in r['Name'] or 'drel' in r['Name']:
+      ks[r['Name'].split('(')[0]] = round(float(r['AverageNs']) / 1e3, 2)
+except OSError:
+  pass
 commit = subprocess.check_output(['git', 'rev-parse', '--short=12', 'HEAD']).decode().strip()
 dirty = bool(subprocess.check_output(['git', 'status', '--porcelain', '--', 'multimodal-long-transformer-2021_amd/csrc']).decode().strip())
 out = {
@@ -27,6 +36,8 @@ out = {
             'WRITE_SIZE as is; unit KB',
   'fwd_hbm_bytes_per_launch': hbm(fwd_k), 'fwd_algorithmic_bytes_per_launch': fb * cfg['B'],
   'bwd_hbm_bytes_per_launch': hbm(bwd_k), 'bwd_algorithmic_bytes_per_launch': bb * cfg['B'],
+  'fwd_kernel_us_rocprof': {k: v for k, v in ks.items() if is_fwd(k)} or None,
+  'bwd_kernel_us_rocprof': {k: v for k, v in ks.items() if not is_fwd(k)} or None,
   'per_kernel_raw_KB': {k: {'FETCH_SIZE': round(f[k], 1), 'WRITE_SIZE': round(w.get(k, 0.0), 1)} for k in f},
 }
 json.dump(out, open('profiles/attn_traffic.json', 'w'), indent=1)
