@@ -383,7 +383,15 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_win_bf16_kernel(const FwdPara
 #ifdef MMT_STAMP
     if (p.dbg_mode & 32) return;
 #endif
-    if ((int)blockIdx.x < n_rows_wg) fwd_rows_body<REL, DROP>(p, smem, (int)blockIdx.x / p.n_rowblk, (int)blockIdx.x % p.n_rowblk);
+    if ((int)blockIdx.x < n_rows_wg) {
+      // rows workgroup i -> (plane, group of 8 rows): on the XCD group that walks the plane's band blocks
+      // (plane_major_map: group x owns planes [x * BN / 8, (x + 1) * BN / 8)), so that the plane's K / V pass through ONE
+      // L2 for both; any assignment is correct
+      const int BN = p.B * p.N, i = (int)blockIdx.x;
+      int item = i;
+      if ((BN & 7) == 0 && (n_rows_wg & 7) == 0) item = (i & 7) * (n_rows_wg >> 3) + (i >> 3);
+      fwd_rows_body<REL, DROP>(p, smem, item / p.n_rowblk, item % p.n_rowblk);
+    }
     return;
   }
 #ifdef MMT_STAMP
