@@ -439,9 +439,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     //     zero dRel)
 #pragma unroll
     for (int rb = 0; rb < Rp / 32; ++rb) {
+      // (unconditional reads from a clamped column, then the select: sixteen exec-masked reads compiled to sixteen
+      //  serialised LDS round trips, 2 k cycles of every workgroup's epilogue -- profiles/r03_bwd_stamps.txt)
       float vals[16];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) vals[i] = rb * 32 + kap(i, h) < dstride ? dtrow[rb * 32 + kap(i, h)] : 0.f;
+      for (int i = 0; i < 16; ++i) vals[i] = dtrow[min(rb * 32 + kap(i, h), dstride - 1)];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(vals[i]));      // (or hipcc sinks each read back under its select)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) vals[i] = rb * 32 + kap(i, h) < dstride ? vals[i] : 0.f;
       mma_xt(a0, a1, VTile<T>{}, elds + rb * 4096, vals, lane);
     }
   }
@@ -483,11 +489,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     f32x16 e0 = {0}, e1 = {0};
     float bsum = 0.f;
     float vals[16];
+    const float* dcol = dtab + 4 * h * dstride + min(col, dstride - 1);     // this lane's column, rows 4h + ...
+    const bool col_ok = id < p.R && col < dstride;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) vals[i] = dcol[((i & 3) + 8 * (i >> 2)) * dstride];   // unconditional reads, then the selects (as above)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(vals[i]));
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int qq = q0 + kap(i, h);
-      const bool use = id < p.R && qq < p.S && !(p.skip_global && is_global(p.pat, qq));
-      vals[i] = (use && col < dstride) ? dtab[kap(i, h) * dstride + col] : 0.f;
+      const bool use = col_ok && qq < p.S && !(p.skip_global && is_global(p.pat, qq));
+      vals[i] = use ? vals[i] : 0.f;
       bsum += vals[i];
     }
     mma_xt(e0, e1, VTile<T>{}, xlds, vals, lane);
