@@ -635,6 +635,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
     vf.v[s] = buf16(rv, (unsigned)r * vs1b + 64 * h + 16 * s, (unsigned)k0 * vs1b);
   }
   bf16x8 qt[4], dot[4];
+  // per-row constants of a q tile (one row per lane): lse, delta, clipped relative score -- fetched ONE TILE AHEAD with
+  // the tile's Q / dO rows.  (They used to be loaded at the top of the tile they belong to, right behind the next
+  // tile's prefetch: two dependent global round trips per tile, each behind a vmcnt(0) that also drained the
+  // prefetch just issued -- the stamps' 6-10 k cycles per tile, profiles/r03_bwd_stamps.txt.)
+  float rc_l = 0.f, rc_d = 0.f, rc_r = 0.f;
+  auto load_rowc = [&](int q0t) {
+    const int qq = min(q0t + r, p.S - 1);
+    rc_l = lse_bn[qq];
+    rc_d = delta_bn[qq];
+    if (REL == 1) rc_r = relfar_bn[2 * qq + h];
+  };
   {
     const unsigned q0 = (unsigned)w.at(0) * 32;
 #pragma unroll
@@ -642,6 +653,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
       qt[u] = buf16(rq, voff_qc, (q0 + 8 * u) * qs1b);
       dot[u] = buf16(rdo, voff_oc, (q0 + 8 * u) * os1b);
     }
+    load_rowc((int)q0);
   }
   KSTAMP(1);
   if (HAS_REL) {           // E image after the item's loads are in flight (see the dQ kernel)
@@ -678,6 +690,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
     asm volatile("" : "+v"(h4));
     tile_to_lds(qlds, qt, lane);
     tile_to_lds(dolds, dot, lane);
+    // per-row constants of this q tile (one row per lane) -> LDS, from the registers filled one tile ago
+    {
+      const float l2 = rc_l * kLog2e;
+      rowc[lane] = h == 0 ? l2 : rc_d;
+      if (REL == 1) rowc[64 + lane] = rc_r - l2;
+    }
     if (it + 1 < n_it) {
       const unsigned q1 = (unsigned)w.at(it + 1) * 32;
 #pragma unroll
@@ -685,13 +703,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
         qt[u] = buf16(rq, voff_qc, (q1 + 8 * u) * qs1b);
         dot[u] = buf16(rdo, voff_oc, (q1 + 8 * u) * os1b);
       }
-    }
-    // per-row constants of this q tile (one row per lane) -> LDS
-    {
-      const int qq = min(q0 + r, p.S - 1);
-      const float l2 = lse_bn[qq] * kLog2e;
-      rowc[lane] = h == 0 ? l2 : delta_bn[qq];
-      if (REL == 1) rowc[64 + lane] = relfar_bn[2 * qq + h] - l2;
+      load_rowc((int)q1);
     }
     const bool no_gq = p.pat.ng == 0 || q0 + 31 < p.pat.g0 || q0 >= p.pat.g0 + p.pat.ng;
     const TileClass tc = classify_tile(q0, k0, p.S, valid_len, W, m, ignore_band, no_gq);
