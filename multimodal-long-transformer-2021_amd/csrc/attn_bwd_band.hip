@@ -720,10 +720,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
         frag_from_tile(ef, elds + rb * 4096, lane);
         f32x16 c = {0};
         c = mma_rows(ef, qf, c);
+        // the sixteen bias values first, then the sixteen stores: interleaved, hipcc kept every read behind the store
+        // before it (it cannot tell the two LDS arrays apart) -- eight serialised LDS round trips per rebuilt tile
+        float bv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) bv[i] = bias_ts[rb * 32 + (i & 3) + 8 * (i >> 2) + h4];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bv[i]));
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int col = rb * 32 + (i & 3) + 8 * (i >> 2) + h4;
-          tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bias_ts[col]) + nl;
+          tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bv[i]) + nl;
         }
       }
       wave_lds_sync();
