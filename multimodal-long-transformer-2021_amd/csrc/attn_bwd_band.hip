@@ -203,10 +203,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
       frag_from_tile(ef, elds + rb * 4096, lane);   // row r <- E row of table column rb*32 + r
       f32x16 c = {0};
       c = mma_rows(ef, qf, c);
+      float bv[16];                      // the bias values in one batch, then the stores (see the dK/dV pass's rebuild)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bv[i] = bias_ts[rb * 32 + kap(i, h)];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bv[i]));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int col = rb * 32 + kap(i, h);
-        tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bias_ts[col]);
+        tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bv[i]);
       }
     }
     wave_lds_sync();

@@ -212,13 +212,20 @@ __device__ __forceinline__ void fwd_rows_body(const FwdParams& p, unsigned char*
       for (int s = 0; s < 4; ++s) kf.v[s] = buf16(rk, voff_kf + 16 * s, (unsigned)(k0 + 32) * ks1b);
     }
     const bool kv = k < valid_len, kin = k < p.S;
-    float s2[4];
+    float s2[4], relv[4] = {0.f, 0.f, 0.f, 0.f};
+    // (one gather per element whatever the distance: for a far key the clamp lands on column 0 or 2m, the same
+    // address in every lane of the half-wave -- a broadcast read.  All four are issued before any is used: left
+    // alone, hipcc sinks each under its element's validity test and waits for it there -- four LDS round trips.)
+    if (HAS_REL) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        relv[i] = *(lds_cfp)(size_t)(unsigned)(tabg_addr + i * tstride * 4 + 4 * med3i(k - (qg0 + 4 * h + i) + m, 0, 2 * m));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(relv[i]));
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float rel = 0.f;
-      // (one gather per element whatever the distance: for a far key the clamp lands on column 0 or 2m, the same
-      // address in every lane of the half-wave -- a broadcast read)
-      if (HAS_REL) rel = *(lds_cfp)(size_t)(unsigned)(tabg_addr + i * tstride * 4 + 4 * med3i(k - (qg0 + 4 * h + i) + m, 0, 2 * m));
+      const float rel = relv[i];
       float sc = fmaf(c[i], p.sscale, rel);
       sc = (kv == qvalid[i]) ? sc : sc + p.mask_add;
       s2[i] = (kin && qin[i]) ? sc : -INFINITY;
@@ -270,8 +277,10 @@ __device__ __forceinline__ void fwd_rows_body(const FwdParams& p, unsigned char*
         {
           const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
           const __bf16* prow = pbuf + (r & 7) * 32 + 16 * s + 4 * h;         // keys {0..3, 8..11} + 4h + 16s
-          const bf16x4 lo = r < 8 ? *reinterpret_cast<const bf16x4*>(prow) : z;
-          const bf16x4 hi = r < 8 ? *reinterpret_cast<const bf16x4*>(prow + 8) : z;
+          s16x4 lo_r = *reinterpret_cast<const s16x4*>(prow), hi_r = *reinterpret_cast<const s16x4*>(prow + 8);   // every lane reads
+          asm volatile("" : "+v"(lo_r), "+v"(hi_r));                         // (a valid row); lanes 8..31 then take zeros
+          const bf16x4 lo = r < 8 ? __builtin_bit_cast(bf16x4, lo_r) : z;
+          const bf16x4 hi = r < 8 ? __builtin_bit_cast(bf16x4, hi_r) : z;
 #pragma unroll
           for (int j = 0; j < 4; ++j) { pf[j] = lo[j]; pf[4 + j] = hi[j]; }
         }
