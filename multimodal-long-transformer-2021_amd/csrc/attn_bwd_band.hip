@@ -246,6 +246,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     Frag<T> kf, vf;
     frag_from_tile(kf, xlds, lane);
     frag_from_tile(vf, vlds, lane);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) asm volatile("" : "+v"(kf.v[s4]), "+v"(vf.v[s4]));   // all eight reads in flight before the first MFMA
     f32x16 c = {0}, dp = {0};
     c = mma_rows(kf, qf, c);      // S^T  [key x q]
     dp = mma_rows(vf, dof, dp);   // dP^T [key x q]
