@@ -148,11 +148,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   TileWalkLean w;
   if (split_item) w.set_chunk(chunk * p.chunk_tiles, min(n_tiles, (chunk + 1) * p.chunk_tiles));
   else w.set_band(p.pat, live ? q0 : 0, p.S);
+  // The (<= 8) global keys outside this wave's band tiles: not a sixth tile of the walk but a PEELED step before it
+  // (registers 0..3 only: a quarter of a tile's VALU work, half of its dQ MFMAs, one K and one V load instruction).
+  const bool peel = REL != 2 && p.peel_gkeys && !split_item && live &&
+                    !(p.pat.g0 >= w.b0 * 32 && p.pat.g0 + p.pat.ng - 1 <= (w.b0 + w.lenB) * 32 - 1);
+  if (REL != 2 && p.peel_gkeys && !split_item) { w.lenA = 0; w.lenC = 0; }
   const int n_it = live ? w.count() : 0;
 
   Frag<T> qf, dof;
-  bf16x8 kt[4], vt[4];
+  bf16x8 kt[4], vt[4], kg, vg;
   float delta;
+  if (peel) {              // rows g0 .. g0 + 7 of K and V, tile shape (rows past the end read as zeros)
+    kg = buf16(rk, voff_kc, (unsigned)p.pat.g0 * ks1b);
+    vg = buf16(rv, voff_vc, (unsigned)p.pat.g0 * vs1b);
+  }
   {
     // the item's own rows and its first K / V tile are requested BEFORE the workgroup stages the E image: the two
     // memory round trips overlap instead of following each other (waves past the end read zeros and leave below)
@@ -237,6 +246,74 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   const int xq2 = (int)__umulhi((unsigned)q, p.pat.magicP), yq2 = q - xq2 * p.pat.P;
   const int lut_addr = lds_addr(lut), dtrow_addr = lds_addr(dtrow);
   const int lim2 = p.pat.r + 1, nlim2 = -lim2;
+
+  if (peel) {
+    {   // the 8 rows into the tile images (rows 0..7); rows 8..15 of the K image as zeros (dS is 0 there, 0 x garbage is not)
+      const int row = lane >> 3, ch = lane & 7;
+      const int off = row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
+      *reinterpret_cast<bf16x8*>(xlds + off) = kg;
+      *reinterpret_cast<bf16x8*>(vlds + off) = vg;
+      const bf16x8 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      *reinterpret_cast<bf16x8*>(xlds + 1024 + off) = z;
+    }
+    wave_lds_sync();
+    const int lo_k = w.b0 * 32, hi_k = (w.b0 + w.lenB) * 32 - 1;          // keys of this wave's band tiles
+    const int kg0 = p.pat.g0, n_here = p.pat.ng;
+    Frag<T> kf, vf;
+    {
+      const int rr = r & 7;                              // rows 8..31 of the "tile" are not used: any finite row
+      const unsigned char* krow = xlds + rr * 128 + ((h ^ ((rr >> 1) & 1)) << 6);
+      const unsigned char* vrow = vlds + rr * 128 + ((h ^ ((rr >> 1) & 1)) << 6);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        kf.v[s] = *reinterpret_cast<const bf16x8*>(krow + s * 16);
+        vf.v[s] = *reinterpret_cast<const bf16x8*>(vrow + s * 16);
+      }
+    }
+    f32x16 c = {0}, dp = {0};
+    c = mma_rows(kf, qf, c);
+    dp = mma_rows(vf, dof, dp);
+    const bool qv = q < valid_len;
+    float ds[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = kg0 + i + 4 * h;
+      const bool present = (i + 4 * h < n_here) && !(kk >= lo_k && kk <= hi_k) && q_ok && kk < p.S;
+      const bool neg = kk < q;                             // beyond the radius on that side: clipped id
+      float sc = fmaf(c[i], p.sscale, HAS_REL ? (neg ? relfn : relfp) : 0.f);
+      sc = ((kk < valid_len) == qv) ? sc : sc + p.mask_add;
+      const float pr = present ? __builtin_amdgcn_exp2f(sc - lse2) : 0.f;
+      float f = 1.f;
+      if (p.drop_thresh) f = drop_bits16(drop_base, (uint32_t)kk) >= p.drop_thresh ? p.inv_keep : 0.f;
+      ds[i] = pr * (dp[i] * f - delta);
+      if (HAS_REL) { far_neg_acc += neg ? ds[i] : 0.f; far_pos_acc += neg ? 0.f : ds[i]; }
+    }
+#pragma unroll
+    for (int i = 4; i < 16; ++i) ds[i] = 0.f;
+    {   // dQ^T += K_g^T . dS^T over rows 0..15 of the image (mma_xt's first key step)
+      const int li = lane & 15, cb = (lane >> 4) & 1;
+      bf16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (__bf16)ds[j];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int row = 4 * h + (li >> 2);
+        const int within = 32 * cb + 8 * (li & 3);
+        const int off0 = row * 128 + ((db ^ ((row >> 1) & 1)) << 6) + within;
+        const int row1 = row + 8;
+        const int off1 = row1 * 128 + ((db ^ ((row1 >> 1) & 1)) << 6) + within;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xlds + off0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xlds + off1));
+        bf16x8 xf;
+        bf16x4 lo4 = __builtin_bit_cast(bf16x4, lo), hi4 = __builtin_bit_cast(bf16x4, hi);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xf[j] = lo4[j]; xf[4 + j] = hi4[j]; }
+        if (db == 0) a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, pf, a0, 0, 0, 0);
+        else a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf, pf, a1, 0, 0, 0);
+      }
+    }
+    wave_lds_sync();                 // the first band tile overwrites the images
+  }
 
   for (int it = 0; it < n_it; ++it) {
     const int k0 = w.at(it) * 32;
