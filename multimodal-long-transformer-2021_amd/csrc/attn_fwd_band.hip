@@ -133,10 +133,15 @@ __global__ __launch_bounds__(256, (Rp == 64 && REL == 2) ? 2 : 3) void attn_fwd_
     for (int rb = 0; rb < Rp / 32; ++rb) {
       f32x16 c = {0};
       c = mma_rows(ef[rb], qf, c);   // [id x q]
+      float bv[16];                  // the sixteen bias values in one batch, then the stores: interleaved, hipcc keeps every
+#pragma unroll                       // read behind the store before it (one LDS round trip each: it cannot tell the arrays apart)
+      for (int i = 0; i < 16; ++i) bv[i] = bias_ts[rb * 32 + kap(i, h)];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(bv[i]));
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int col = rb * 32 + kap(i, h);
-        tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bias_ts[col]);
+        tab[r * kTStride(Rp) + col] = fmaf(c[i], p.tscale, bv[i]);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
