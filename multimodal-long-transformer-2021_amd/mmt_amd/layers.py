@@ -518,9 +518,16 @@ class MaskedLM(nn.Module):
   def forward(self, sequence_data, masked_positions, gathered=None):
     # `gathered`: rows already picked by the caller's single merged gather (models.py)
     x = gather_indexes(sequence_data, masked_positions) if gathered is None else gathered
-    x = _linear(x, self.dense_weight, self.dense_bias)
-    if self.activation is not None:
-      x = self.activation(x)
+    if (self.activation is _GELU_TANH and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2
+        and torch.is_grad_enabled()):
+      # dense without its bias, then bias + tanh-GELU in the encoder's fused kernel (forward and backward one pass
+      # each, the bias gradient by the column-sum kernel) instead of the framework's GELU pair
+      # (`mmt_pretraining_model.py:91-103`: MaskedLM = dense + activation + LayerNorm + tied logits)
+      x = fused.bias_gelu(_linear(x, self.dense_weight, None), self.dense_bias)
+    else:
+      x = _linear(x, self.dense_weight, self.dense_bias)
+      if self.activation is not None:
+        x = self.activation(x)
     x = _head_layer_norm(self.layer_norm, x)
     # the tied table also receives the embedding-lookup gradient through plain autograd, so it
     # must not use the accumulate-in-backward cast (one gradient-ready event per parameter)
