@@ -150,9 +150,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   else w.set_band(p.pat, live ? q0 : 0, p.S);
   // The (<= 8) global keys outside this wave's band tiles: not a sixth tile of the walk but a PEELED step before it
   // (registers 0..3 only: a quarter of a tile's VALU work, half of its dQ MFMAs, one K and one V load instruction).
-  const bool peel = REL != 2 && p.peel_gkeys && !split_item && live &&
+  const bool peel = REL != 2 && (p.peel_gkeys & 1) && !split_item && live &&
                     !(p.pat.g0 >= w.b0 * 32 && p.pat.g0 + p.pat.ng - 1 <= (w.b0 + w.lenB) * 32 - 1);
-  if (REL != 2 && p.peel_gkeys && !split_item) { w.lenA = 0; w.lenC = 0; }
+  if (REL != 2 && (p.peel_gkeys & 1) && !split_item) { w.lenA = 0; w.lenC = 0; }
   const int n_it = live ? w.count() : 0;
 
   Frag<T> qf, dof;
@@ -710,6 +710,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   TileWalkLean w;
   if (split_item) w.set_chunk(chunk * p.chunk_tiles, min(n_tiles, (chunk + 1) * p.chunk_tiles));
   else w.set_band(p.pat, live ? k0 : 0, p.S);
+  // The (<= 8) global query ROWS outside this wave's band q tiles: a PEELED step before the walk instead of a sixth
+  // q tile (registers 0..3 only; one load instruction each for their Q and dO rows) -- the mirror of the dQ pass's
+  // peeled global keys.
+  const bool peel = REL != 2 && (p.peel_gkeys & 2) && !split_item && live &&
+                    !(p.pat.g0 >= w.b0 * 32 && p.pat.g0 + p.pat.ng - 1 <= (w.b0 + w.lenB) * 32 - 1);
+  if (REL != 2 && (p.peel_gkeys & 2) && !split_item) { w.lenA = 0; w.lenC = 0; }
   const int n_it = live ? w.count() : 0;
 
   Frag<T> kf, vf;
@@ -763,6 +769,91 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
   const int tab_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)tab;
   const uint32_t bn_seed = mix32(p.seed_lo ^ ((uint32_t)bn * 0x9E3779B9u)) + p.seed_hi;
   const uint32_t drop_kterm = (uint32_t)(k >> 1) * kDropPairMul, drop_ksh = (k & 1) ? 16u : 0u;   // this lane's key
+
+  if (peel) {
+    // rows g0 .. g0 + 7 of Q and dO (tile shape; rows past the end read as zeros) and their row constants
+    const bf16x8 qg = buf16(rq, voff_qc, (unsigned)p.pat.g0 * qs1b);
+    const bf16x8 dog = buf16(rdo, voff_oc, (unsigned)p.pat.g0 * os1b);
+    const int qq = min(p.pat.g0 + r, p.S - 1);
+    const float g_l2 = lse_bn[qq] * kLog2e, g_dl = delta_bn[qq];
+    const float g_rf = REL == 1 ? relfar_bn[2 * qq + h] : 0.f;
+    {
+      const int row = lane >> 3, ch = lane & 7;
+      const int off = row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
+      const bf16x8 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      *reinterpret_cast<bf16x8*>(qlds + off) = qg;           // rows 0..7
+      *reinterpret_cast<bf16x8*>(dolds + off) = dog;
+      *reinterpret_cast<bf16x8*>(qlds + 1024 + off) = z;     // rows 8..15: P and dS are 0 there, 0 x garbage is not
+      *reinterpret_cast<bf16x8*>(dolds + 1024 + off) = z;
+      rowc[lane] = h == 0 ? g_l2 : g_dl;
+      if (REL == 1) rowc[64 + lane] = g_rf - g_l2;
+    }
+    wave_lds_sync();
+    const int lo_q = w.b0 * 32, hi_q = (w.b0 + w.lenB) * 32 - 1;          // q rows of this wave's band tiles
+    const int qg0 = p.pat.g0, n_here = p.pat.ng;
+    Frag<T> qgf, dogf;
+    {
+      const int rr = r & 7;
+      const unsigned char* qrow = qlds + rr * 128 + ((h ^ ((rr >> 1) & 1)) << 6);
+      const unsigned char* drow = dolds + rr * 128 + ((h ^ ((rr >> 1) & 1)) << 6);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qgf.v[s] = *reinterpret_cast<const bf16x8*>(qrow + s * 16);
+        dogf.v[s] = *reinterpret_cast<const bf16x8*>(drow + s * 16);
+      }
+    }
+    f32x16 c = {0}, dp = {0};
+    c = mma_rows(qgf, kf, c);            // S  [q x key]: registers 0..3 = global rows 4h + i
+    dp = mma_rows(dogf, vf, dp);         // dP [q x key]
+    // a peeled row lies beyond the radius (>= max_dist) from every key of this wave: clipped id, by the side it is on
+    const bool kv = k < valid_len;
+    float pr[16], g[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i + 4 * h, qrow_abs = qg0 + row;
+      const bool present = row < n_here && !(qrow_abs >= lo_q && qrow_abs <= hi_q) && k_ok;
+      const float rl = HAS_REL ? rowc[(k < qrow_abs ? 64 : 96) + row] : -rowc[row];     // key < query: d <= -m
+      float sc = fmaf(c[i], p.sscale, rl);
+      sc = (kv == (qrow_abs < valid_len)) ? sc : sc + p.mask_add;
+      float pv = present ? __builtin_amdgcn_exp2f(sc) : 0.f;
+      float df = 1.f;
+      if (p.drop_thresh) {
+        const uint32_t hsh = drop_pair_finish(bn_seed + (uint32_t)qrow_abs * 0x85EBCA6Bu, drop_kterm);
+        df = ((hsh >> drop_ksh) & 0xFFFFu) >= p.drop_thresh ? p.inv_keep : 0.f;
+      }
+      g[i] = pv * (dp[i] * df - rowc[32 + row]);
+      pr[i] = pv * df;
+    }
+#pragma unroll
+    for (int i = 4; i < 16; ++i) { pr[i] = 0.f; g[i] = 0.f; }
+    {   // dV^T += dO_g^T . P and dK^T += Q_g^T . dS over rows 0..15 of the images (mma_xt's first q step)
+      const int li = lane & 15, cb = (lane >> 4) & 1;
+      bf16x8 pf, gf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { pf[j] = (__bf16)pr[j]; gf[j] = (__bf16)g[j]; }
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int row = 4 * h + (li >> 2);
+        const int within = 32 * cb + 8 * (li & 3);
+        const int off0 = row * 128 + ((db ^ ((row >> 1) & 1)) << 6) + within;
+        const int row1 = row + 8;
+        const int off1 = row1 * 128 + ((db ^ ((row1 >> 1) & 1)) << 6) + within;
+        auto tr = [&](const unsigned char* img) {
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + off0));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + off1));
+          bf16x8 xf;
+          bf16x4 lo4 = __builtin_bit_cast(bf16x4, lo), hi4 = __builtin_bit_cast(bf16x4, hi);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { xf[j] = lo4[j]; xf[4 + j] = hi4[j]; }
+          return xf;
+        };
+        const bf16x8 dof_t = tr(dolds), qf_t = tr(qlds);
+        if (db == 0) { dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof_t, pf, dv0, 0, 0, 0); dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf_t, gf, dk0, 0, 0, 0); }
+        else { dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof_t, pf, dv1, 0, 0, 0); dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf_t, gf, dk1, 0, 0, 0); }
+      }
+    }
+    wave_lds_sync();                 // the first band tile overwrites the images and the row constants
+  }
 
   for (int it = 0; it < n_it; ++it) {
     const int q0 = w.at(it) * 32;

@@ -75,7 +75,7 @@ struct BwdParams {
   float* part_dkv;   // [B*N, n_gblk, n_chunks, 2, 32, 64] global-key partials
   float* part_red;   // [B*N * ceil(S/128) * 4 waves, Rp*64 + Rp]  per-wave dE^T / dbias partials
   int n_band_blocks, n_chunks, chunk_tiles, n_gblk, n_split;
-  int peel_gkeys;       // lean dQ pass: the (<= 8) global keys outside a wave's band tiles as a peeled quarter-tile step
+  int peel_gkeys;       // bit 0, dQ pass: the (<= 8) global keys outside a wave's band tiles as a peeled quarter-tile step; bit 1, dK/dV pass: the global query rows likewise
   int dq_plane_major;   // dQ pass: plane-major block placement (attn_lean.h) instead of long-items-first + XCD remap
   long long* dbg;    // -DMMT_STAMP diagnostic builds only (see FwdParams)
   int dbg_mode;

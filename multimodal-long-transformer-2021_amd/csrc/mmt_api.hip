@@ -285,8 +285,8 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   }
   if (const char* v = std::getenv("MMT_DQ_PLANE_MAJOR")) p.dq_plane_major = std::atoi(v);
   // peeled global keys need clipped relative ids only: every peeled key lies beyond the radius, hence beyond max_dist
-  p.peel_gkeys = (!dense && pl.split_rows && p.pat.ng <= 8 && (p.pat.id_mode == 0 || (p.perm_1d && p.pat.radius >= p.pat.m))) ? 1 : 0;
-  if (const char* v = std::getenv("MMT_BWD_PEEL")) p.peel_gkeys = p.peel_gkeys && std::atoi(v);
+  p.peel_gkeys = (!dense && pl.split_rows && p.pat.ng <= 8 && (p.pat.id_mode == 0 || (p.perm_1d && p.pat.radius >= p.pat.m))) ? 3 : 0;
+  if (const char* v = std::getenv("MMT_BWD_PEEL")) p.peel_gkeys &= std::atoi(v);      // bit 0: dQ pass, bit 1: dK/dV pass
 #ifdef MMT_STAMP
   if (const char* v = std::getenv("MMT_DBG_PTR")) p.dbg = reinterpret_cast<long long*>(std::strtoull(v, nullptr, 0));
   if (const char* v = std::getenv("MMT_DBG_MODE")) p.dbg_mode = std::atoi(v);
