@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dkv_ke
   }
 
   if (split_item) {
-    const long slot = ((long)bn * p.n_gblk + gblk) * p.n_chunks + chunk;
+    const long slot = ((long)bn * p.n_gblk + gblk) * p.dkv_slots + chunk;
     float* pk = p.part_dkv + slot * (2 * 32 * 64) + r * 64;
     float* pv2 = pk + 32 * 64;
 #pragma unroll

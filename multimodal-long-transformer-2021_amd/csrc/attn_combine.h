@@ -42,24 +42,24 @@ __device__ __forceinline__ void dq_combine_row(const BwdParams& p, int bn, int r
   DQ[d] = (T)acc;
 }
 
-// dK / dV rows of global token `row` of plane bn: sum of the chunk partials.
+// dK / dV rows of global token `row` of plane bn: sum of the chunk partials (p.dkv_slots of them, in slot order).
 template <typename T>
 __device__ __forceinline__ void dkv_combine_row(const BwdParams& p, int bn, int row, int d) {
   const int gblk = row >> 5, rr = row & 31;
   const int b = bn / p.N, n = bn - b * p.N;
   const int k = p.pat.g0 + row;
-  const long slot0 = ((long)bn * p.n_gblk + gblk) * p.n_chunks;
+  const long slot0 = ((long)bn * p.n_gblk + gblk) * p.dkv_slots;
   float ak = 0.f, av = 0.f;
   const float* base = p.part_dkv + slot0 * (2 * 32 * 64) + rr * 64 + d;
   int c = 0;
-  for (; c + 4 <= p.n_chunks; c += 4) {
+  for (; c + 4 <= p.dkv_slots; c += 4) {
     float a[4], t[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) { a[u] = base[(long)(c + u) * (2 * 32 * 64)]; t[u] = base[(long)(c + u) * (2 * 32 * 64) + 32 * 64]; }
 #pragma unroll
     for (int u = 0; u < 4; ++u) { ak += a[u]; av += t[u]; }
   }
-  for (; c < p.n_chunks; ++c) { ak += base[(long)c * (2 * 32 * 64)]; av += base[(long)c * (2 * 32 * 64) + 32 * 64]; }
+  for (; c < p.dkv_slots; ++c) { ak += base[(long)c * (2 * 32 * 64)]; av += base[(long)c * (2 * 32 * 64) + 32 * 64]; }
   reinterpret_cast<T*>(p.dk)[(long)b * p.ks[0] + (long)k * p.ks[1] + (long)n * p.ks[2] + d] = (T)ak;
   reinterpret_cast<T*>(p.dv)[(long)b * p.vs[0] + (long)k * p.vs[1] + (long)n * p.vs[2] + d] = (T)av;
 }

@@ -72,10 +72,19 @@ struct BwdParams {
   float* drel;       // [B*N, n_global, Rp]  d(relall) rows of the global tokens, id order
   float* part_dq;    // [B*N, n_gblk, n_chunks, 32, 64]   global-row partials
   float* part_dtab;  // [B*N, n_gblk, n_chunks, 32, Rp]
-  float* part_dkv;   // [B*N, n_gblk, n_chunks, 2, 32, 64] global-key partials
+  float* part_dkv;   // [B*N, n_gblk, dkv_slots, 2, 32, 64] global-key partials
   float* part_red;   // [B*N * ceil(S/128) * 4 waves, Rp*64 + Rp]  per-wave dE^T / dbias partials
   int n_band_blocks, n_chunks, chunk_tiles, n_gblk, n_split;
   int peel_gkeys;       // bit 0, dQ pass: the (<= 8) global keys outside a wave's band tiles as a peeled quarter-tile step; bit 1, dK/dV pass: the global query rows likewise
+  // P / dS hand-over (lean bf16 path): the dQ pass stores every tile's P' (dropout applied) and dS as bf16 and the
+  // dK/dV pass (attn_bwd_dkv_ho_kernel) contracts them with dO / Q instead of recomputing S, dP, the exponentials
+  // and the keep hashes.  Regions of `ho` (bytes): band tiles [B*N][n_tiles q blocks][ho_slots][P 2 KiB | dS 2 KiB],
+  // then global-key strips [B*N][n_tiles q blocks][P 512 | dS 512] (32 rows x 8 keys), then global-row tiles
+  // [B*N][n_tiles key blocks][P 512 | dS 512] (8 rows x 32 keys).  NULL = off.
+  unsigned char* ho;
+  int ho_slots;         // band key tiles per 32-row q block: 2 * ceil(radius / 32) + 1
+  int dkv_slots;        // partial slots per (plane, global block) in part_dkv: n_chunks, + 1 with the hand-over (the
+                        // band part of the global keys, written by the band key waves)
   int dq_plane_major;   // dQ pass: plane-major block placement (attn_lean.h) instead of long-items-first + XCD remap
   long long* dbg;    // -DMMT_STAMP diagnostic builds only (see FwdParams)
   int dbg_mode;

@@ -40,7 +40,19 @@ struct Plan {
   size_t bwd_ws;
   int n_split;
   size_t off_delta, off_relfar, off_drel, off_pdq, off_pdtab, off_pdkv, off_red;  // float offsets
+  size_t off_ho;     // float offset of the P / dS hand-over region (attn_kernels.h), 0 bytes when the shape has none
+  int ho_slots;      // band key tiles per q block there (0 = no hand-over for this shape)
 };
+
+// P / dS hand-over between the two backward passes (lean bf16 kernels, 1-D or no relative ids): shapes it is built for.
+// The global tokens, if any, must be the peeled kind (<= 8, contiguous); the band at most 8 tiles wide.
+int handover_slots(const mmt_attn_desc* d, bool dense) {
+  if (dense || d->dtype != MMT_BF16 || d->mask.id_mode == MMT_IDS_2D) return 0;
+  if (d->mask.global_index || d->mask.n_global > 8) return 0;
+  const int W = d->mask.local_radius > d->S ? d->S : d->mask.local_radius;
+  const int slots = 2 * ((W + 31) / 32) + 1;
+  return slots <= 8 ? slots : 0;
+}
 
 int check_desc(const mmt_attn_desc* d) {
   if (!d) return fail(MMT_E_INVALID, "desc is NULL");
@@ -101,8 +113,11 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
   pl.off_pdq = pl.off_drel + bn * (size_t)d->mask.n_global * Rp;
   pl.off_pdtab = pl.off_pdq + bn * pl.n_rowblk * pl.n_chunks * (32 * 64);
   pl.off_pdkv = pl.off_pdtab + bn * pl.n_rowblk * pl.n_chunks * (32 * Rp);
-  pl.off_red = pl.off_pdkv + bn * pl.n_rowblk * pl.n_chunks * (2 * 32 * 64);
-  pl.bwd_ws = (pl.off_red + bn * ((d->S + 127) / 128) * 4 * (Rp * 64 + Rp)) * sizeof(float);
+  pl.off_red = pl.off_pdkv + bn * pl.n_rowblk * (pl.n_chunks + 1) * (2 * 32 * 64);      // (+ 1: the hand-over's band slot)
+  pl.off_ho = (pl.off_red + bn * ((d->S + 127) / 128) * 4 * (Rp * 64 + Rp) + 3) & ~(size_t)3;
+  pl.ho_slots = handover_slots(d, dense);
+  const size_t ho_bytes = pl.ho_slots ? bn * n_tiles * ((size_t)pl.ho_slots * 4096 + 2048) : 0;
+  pl.bwd_ws = pl.off_ho * sizeof(float) + ho_bytes;
   return pl;
 }
 
@@ -287,6 +302,17 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   // peeled global keys need clipped relative ids only: every peeled key lies beyond the radius, hence beyond max_dist
   p.peel_gkeys = (!dense && pl.split_rows && p.pat.ng <= 8 && (p.pat.id_mode == 0 || (p.perm_1d && p.pat.radius >= p.pat.m))) ? 3 : 0;
   if (const char* v = std::getenv("MMT_BWD_PEEL")) p.peel_gkeys &= std::atoi(v);      // bit 0: dQ pass, bit 1: dK/dV pass
+  p.dkv_slots = p.n_chunks;
+  {   // P / dS hand-over: the dK/dV pass reads what the dQ pass computed (needs the peeled kind of global tokens, if any)
+    int on = 1;
+    if (const char* v = std::getenv("MMT_BWD_HANDOVER")) on = std::atoi(v);
+    const bool lean = desc->dtype == MMT_BF16 && !dense && (p.pat.id_mode == 0 || p.perm_1d);
+    if (on && lean && pl.ho_slots > 0 && (p.pat.ng == 0 || !pl.split_rows || (p.peel_gkeys & 1))) {
+      p.ho = reinterpret_cast<unsigned char*>(ws + pl.off_ho);
+      p.ho_slots = pl.ho_slots;
+      if (pl.split_rows) p.dkv_slots = p.n_chunks + 1;
+    }
+  }
 #ifdef MMT_STAMP
   if (const char* v = std::getenv("MMT_DBG_PTR")) p.dbg = reinterpret_cast<long long*>(std::strtoull(v, nullptr, 0));
   if (const char* v = std::getenv("MMT_DBG_MODE")) p.dbg_mode = std::atoi(v);
