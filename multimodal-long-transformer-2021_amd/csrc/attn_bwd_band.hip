@@ -55,13 +55,16 @@ __device__ __forceinline__ void lds_add_f32(int addr, float v) {
   asm volatile("ds_add_f32 %0, %1" : : "v"(addr), "v"(v) : "memory");
 }
 
-// ---- P / dS hand-over between the passes (BwdParams::ho) ------------------------------------------------------------
+// ---- P hand-over between the passes (BwdParams::ho) ----------------------------------------------------------------
+// The dQ pass stores every tile's probabilities as bf16, the SIGN bit carrying the dropout decision (set = dropped; P is
+// never negative), and the dK/dV pass rebuilds P' = keep ? P / keep_prob : 0 and dS = P (dP' - delta) from them: dP is one
+// more MFMA group there, the scores, the exponentials, the relative ids, the masks and the keep hashes are not redone.
 // A 32 x 32 tile is stored the way the dQ pass holds it (lane = query row r, half h, registers 8 g .. 8 g + 7 = keys
 // 16 g + 4 h + {0..3, 8..11}): four blocks (2 g + h) of 512 bytes, row r of a block in the 16-byte unit r ^ (block << 2),
 // its keys +0..3 in the first and +8..11 in the second 8 bytes.  One store instruction writes a contiguous KiB, and the
 // dK/dV pass's transposed LDS reads (four rows x four 4-key chunks per 16 lanes) find their chunks in different banks.
 // Global-row tiles (8 rows x 32 keys): [block][row][16 bytes]; global-key strips (32 rows x 8 keys): [h][row][8 bytes].
-constexpr int kHoTile = 4096, kHoStrip = 1024;          // P' image then dS image (2048 + 2048 / 512 + 512 bytes)
+constexpr int kHoTile = 2048, kHoStrip = 512;
 __device__ __forceinline__ int ho_unit_off(int blk, int q) { return blk * 512 + ((q ^ (blk << 2)) << 4); }
 __device__ __forceinline__ size_t ho_band_plane(const BwdParams& p, int n_tiles) { return (size_t)n_tiles * p.ho_slots * kHoTile; }
 __device__ __forceinline__ unsigned char* ho_band_base(const BwdParams& p, int n_tiles, int bn) {          // [q block][slot] tiles of a plane
@@ -74,8 +77,11 @@ __device__ __forceinline__ unsigned char* ho_grow_base(const BwdParams& p, int n
   return p.ho + (size_t)p.B * p.N * (ho_band_plane(p, n_tiles) + (size_t)n_tiles * kHoStrip) + (size_t)bn * n_tiles * kHoStrip;
 }
 __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) { return bf16x4{(__bf16)a, (__bf16)b, (__bf16)c, (__bf16)d}; }
+#ifndef MMT_HO_AUX
+#define MMT_HO_AUX 2          // nt: written once, read once by the next kernel -- keep it out of the way of the K / V / Q lines in L2
+#endif
 __device__ __forceinline__ void buf_store16(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, const bf16x8& v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, voff, soff, MMT_HO_AUX);
 }
 
 // =========================================================================================
@@ -271,11 +277,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   const int lut_addr = lds_addr(lut), dtrow_addr = lds_addr(dtrow);
   const int lim2 = p.pat.r + 1, nlim2 = -lim2;
 
-  // P / dS hand-over: a tile's two images wait in registers and are stored in the NEXT tile step, ahead of its
-  // prefetch loads.  vmcnt counts loads and stores in issue order, and hipcc waits for the prefetched K / V tile with
-  // vmcnt(0) at the loop top: stores issued behind the prefetch would expose their full latency there once per tile
-  // (+12 us per call when they were).
-  bf16x8 hold_p[2], hold_s[2];
+  // P hand-over: a tile's image waits in registers and is stored in the NEXT tile step, ahead of that step's prefetch
+  // loads: vmcnt counts loads and stores in issue order and hipcc waits for the prefetched K / V tile with vmcnt(0) at
+  // the loop top, so stores issued behind the prefetch would be waited for there, one tile step after they were issued.
+  bf16x8 hold_p[2];
   unsigned hold_so = 0;          // byte offset of the held tile inside the plane's region
   // band waves: the plane's [q block][slot] tiles; global-row items: its [key block] 8-row tiles (rows past the last
   // global token stay unwritten: the dK/dV pass reads them as zeros of its own)
@@ -283,15 +288,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
                              p.ho ? (unsigned)(split_item ? n_tiles * kHoStrip : ho_band_plane(p, n_tiles)) : 0u);
   unsigned hoff0 = split_item ? (r < p.pat.ng ? h * 128 + r * 16 : 0x80000000u) : ho_unit_off(h, r);          // g = 0; (out of range: no store)
   unsigned hoff1 = split_item ? (r < p.pat.ng ? (2 + h) * 128 + r * 16 : 0x80000000u) : ho_unit_off(2 + h, r);  // g = 1
-  const unsigned hold_ds = split_item ? 512 : 2048;
-#ifdef MMT_HO_NOSTORE
-  hoff0 |= 0x80000000u; hoff1 |= 0x80000000u;
-#endif
   auto ho_flush = [&]() {
     buf_store16(rho, hoff0, hold_so, hold_p[0]);
     buf_store16(rho, hoff1, hold_so, hold_p[1]);
-    buf_store16(rho, hoff0 + hold_ds, hold_so, hold_s[0]);
-    buf_store16(rho, hoff1 + hold_ds, hold_so, hold_s[1]);
   };
 
   if (peel) {
@@ -333,13 +332,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
       float f = 1.f;
       if (p.drop_thresh) f = drop_bits16(drop_base, (uint32_t)kk) >= p.drop_thresh ? p.inv_keep : 0.f;
       ds[i] = pr * (dp[i] * f - delta);
-      pd4[i] = pr * f;
+      pd4[i] = f != 0.f ? pr : -pr;
       if (HAS_REL) { far_neg_acc += neg ? ds[i] : 0.f; far_pos_acc += neg ? 0.f : ds[i]; }
     }
     if (p.ho) {              // the strip of this q block: rows x the 8 global keys (zeros where a band tile holds the pair)
       unsigned char* sp = ho_strip(p, n_tiles, bn, q0 >> 5) + lane * 8;
       *reinterpret_cast<bf16x4*>(sp) = pack4(pd4[0], pd4[1], pd4[2], pd4[3]);
-      *reinterpret_cast<bf16x4*>(sp + 512) = pack4(ds[0], ds[1], ds[2], ds[3]);
     }
 #pragma unroll
     for (int i = 4; i < 16; ++i) ds[i] = 0.f;
@@ -369,7 +367,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   } else if (p.ho && p.n_gblk > 0 && !split_item) {       // every global key sits in this wave's band tiles: an empty strip
     unsigned char* sp = ho_strip(p, n_tiles, bn, q0 >> 5) + lane * 8;
     *reinterpret_cast<bf16x4*>(sp) = pack4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<bf16x4*>(sp + 512) = pack4(0.f, 0.f, 0.f, 0.f);
   }
 
   for (int it = 0; it < n_it; ++it) {
@@ -501,17 +498,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
         const float f1 = (hsh >> 16) >= p.drop_thresh ? p.inv_keep : 0.f;
         ds[i] = pr[i] * (dp[i] * f0 - delta);
         ds[i + 1] = pr[i + 1] * (dp[i + 1] * f1 - delta);
-        if (p.ho) { pr[i] *= f0; pr[i + 1] *= f1; }
+        if (p.ho) { pr[i] = f0 != 0.f ? pr[i] : -pr[i]; pr[i + 1] = f1 != 0.f ? pr[i + 1] : -pr[i + 1]; }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) ds[i] = pr[i] * (dp[i] - delta);
     }
-    if (p.ho) {        // hand the tile to the dK/dV pass: P' and dS as bf16 -- stored one tile later (ho_flush)
+    if (p.ho) {        // hand the tile to the dK/dV pass: P as bf16, sign = dropped -- stored one tile later (ho_flush)
 #pragma unroll
       for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { hold_p[g][j] = (__bf16)pr[8 * g + j]; hold_s[g][j] = (__bf16)ds[8 * g + j]; }
+        for (int j = 0; j < 8; ++j) hold_p[g][j] = (__bf16)pr[8 * g + j];
       hold_so = split_item ? (unsigned)(k0 >> 5) * kHoStrip : (unsigned)((q0 >> 5) * p.ho_slots + it) * kHoTile;
     }
     // dRel (unscaled; rel_gscale applied at the flush / in the stores)
@@ -1140,20 +1137,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
 }
 
 // =========================================================================================
-// dK, dV from the hand-over (lane = key).  What the dQ pass computed for a (q tile, key tile) pair -- P' and dS as bf16
-// images -- is contracted with the dO / Q tiles: no scores, no exponentials, no keep hashes, no relative ids here.
+// dK, dV from the hand-over (lane = key, registers = query rows).  Per (q tile, key tile) pair the dQ pass left the
+// probabilities as a bf16 image, sign = dropped; here dP = dO . V^T is one MFMA group, P' = max(x, 0) (scaled by
+// 1 / keep_prob once, at the end), dS = |x| (dP' - delta): no scores, no exponentials, no relative ids, no masks, no
+// keep hashes.
 //   band key wave  : its (up to ho_slots) band q tiles + the 8-row image of the global query rows for its keys;
 //                    the rows of its global keys go to partial slot n_chunks of part_dkv instead of dK / dV
 //   global-key item: the strips (32 rows x 8 keys) of the q blocks of its chunk
 // Rows of global queries inside band tiles / strips are zeroed here (the dQ pass computes and discards them: those
 // pairs belong to the global-row items).
-// The pass is a stream of independent loads with almost no arithmetic behind them, so what it needs is bytes in flight:
-//   WIN = false: every wave stages its own Q / dO tile per step, one step ahead (three workgroups per CU);
+// The pass is a stream of independent loads with little arithmetic behind them, so what it needs is bytes in flight:
+//   WIN = false: every wave stages its own Q / dO tile per step, one step ahead;
 //   WIN = true : (ho_slots <= 5) the band workgroup stages the Q / dO rows of its whole q window -- at most 8 tiles,
-//                64 KiB -- ONCE, and every wave requests all of its (<= 5) image pairs before anything else.
+//                64 KiB -- ONCE, and every wave requests all of its (<= 5) images before anything else.
 // =========================================================================================
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int kHoWaveLds = 2 * 4096 + 2048 + 128;       // per-wave form: Q tile, dO tile, P image, delta of the tile's rows
+constexpr int kHoWinLds = 16 * 4096 + 1024 + 4 * 3072;  // window form: Q window, dO window, delta of its rows, 3 KiB per wave
+
 template <bool WIN>
-__global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const BwdParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_ho_kernel(const BwdParams p) {
   using T = __bf16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -1187,16 +1190,27 @@ __global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const
   }
   const bool win_item = WIN && !split_item;
   if (!live && !win_item) return;
+#ifdef MMT_STAMP
+  long long* dbg = (p.dbg && (p.dbg_mode & 1) == 1 && blockIdx.x == 900) ? p.dbg + wave * 32 : nullptr;
+#define HSTAMP(i) do { if (dbg && lane == 0) dbg[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HSTAMP(i) do { } while (0)
+#endif
+  HSTAMP(0);
   const int b = bn / p.N, n = bn - b * p.N;
   const int k = k0 + r;
   const int W = p.pat.radius;
   const int g0 = p.pat.g0, ng = p.n_gblk > 0 ? p.pat.ng : 0;     // global tokens handled by split items (0: none)
+  const float ik = p.drop_thresh ? p.inv_keep : 1.f;
 
-  const unsigned qs1b = (unsigned)p.qs[1] * 2, os1b = (unsigned)p.os[1] * 2;
+  const unsigned qs1b = (unsigned)p.qs[1] * 2, vs1b = (unsigned)p.vs[1] * 2, os1b = (unsigned)p.os[1] * 2;
   const T* Qb = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)n * p.qs[2];
+  const T* Vb = reinterpret_cast<const T*>(p.v) + (long)b * p.vs[0] + (long)n * p.vs[2];
   const T* DOb = reinterpret_cast<const T*>(p.dout) + (long)b * p.os[0] + (long)n * p.os[2];
   const auto rq = make_rsrc(Qb, (unsigned)(p.S - 1) * qs1b + 128);
+  const auto rv = make_rsrc(Vb, (unsigned)(p.S - 1) * vs1b + 128);
   const auto rdo = make_rsrc(DOb, (unsigned)(p.S - 1) * os1b + 128);
+  const float* delta_bn = p.delta + ((long)b * p.N + n) * p.S;
   const unsigned voff_qc = (unsigned)(lane >> 3) * qs1b + (lane & 7) * 16;
   const unsigned voff_oc = (unsigned)(lane >> 3) * os1b + (lane & 7) * 16;
 
@@ -1205,10 +1219,13 @@ __global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const
   else if (live) { t0 = max(k0 - W, 0) >> 5; n_it = (min(k0 + 31 + W, p.S - 1) >> 5) - t0 + 1; }
   const int kb = k0 >> 5;
   const unsigned char* band_base = ho_band_base(p, n_tiles, bn);
-  auto band_tile = [&](int qb) {         // this key block's image pair in q block qb
+  auto band_tile = [&](int qb) {         // this key block's image in q block qb
     const int slot = kb - (max(qb * 32 - W, 0) >> 5);
     return band_base + (size_t)(qb * p.ho_slots + slot) * kHoTile + lane * 16;
   };
+  Frag<T> vf;                    // this wave's V rows (rows past the end read as zeros)
+#pragma unroll
+  for (int s = 0; s < 4; ++s) vf.v[s] = buf16(rv, (unsigned)r * vs1b + 64 * h + 16 * s, (unsigned)k0 * vs1b);
 
   auto tr = [&](const unsigned char* a) {
     return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a));
@@ -1222,7 +1239,7 @@ __global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const
   const bf16x4 z4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
   // one 16-row step of both products: dV^T[d x key] += dO^T[d x q] . P'[q x key], dK^T += Q^T . dS, A operands by
-  // transposed reads of the tile images (rows 16 s + 4 h + j, + 8: the order of the B registers).  HI = false: rows
+  // transposed reads of the tile images (rows 16 s + 4 h + j, + 8: the order of the B registers).  hi = false: rows
   // 8..15 of the step do not exist (the 8 global rows): zeros instead of the second read.
   auto step = [&](const unsigned char* qimg, const unsigned char* doimg, int s, const bf16x8& pf, const bf16x8& gf, bool hi) {
 #pragma unroll
@@ -1237,45 +1254,92 @@ __global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const
       else { dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof_t, pf, dv1, 0, 0, 0); dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf_t, gf, dk1, 0, 0, 0); }
     }
   };
-  // the B registers of step s from a band image pair / a strip pair in LDS, global-query rows zeroed
-  auto b_regs = [&](const unsigned char* plds, const unsigned char* slds, int s, int q0, bool strip, bf16x8& pf, bf16x8& gf) {
+  // the signed-P registers of step s (element j <-> row 16 s + 4 h + (j & 3) + 8 (j >> 2), the accumulator order) from a
+  // band image / a strip in LDS, rows of global queries zeroed
+  auto x_regs = [&](const unsigned char* plds, int s, int q0, bool strip) {
     const int qr = 16 * s + 4 * h + (li >> 2);
+    bf16x8 px;
     if (strip) {          // [key half][row][4 keys]: lanes past key 7 read copies (their columns are not used)
       const int off = (li & 1) * 256 + qr * 8;
-      pf = join(tr(plds + off), tr(plds + off + 64));
-      gf = join(tr(slds + off), tr(slds + off + 64));
+      px = join(tr(plds + off), tr(plds + off + 64));
     } else {
       const int bk = 2 * cb + (li & 1), sub = ((li >> 1) & 1) * 8;      // chunk li & 3 = keys 16 cb + 4 (li & 3) .. = block bk, half sub
-      const int off0 = ho_unit_off(bk, qr) + sub, off1 = ho_unit_off(bk, qr + 8) + sub;
-      pf = join(tr(plds + off0), tr(plds + off1));
-      gf = join(tr(slds + off0), tr(slds + off1));
+      px = join(tr(plds + ho_unit_off(bk, qr) + sub), tr(plds + ho_unit_off(bk, qr + 8) + sub));
     }
     if (ng > 0 && q0 + 31 >= g0 && q0 < g0 + ng) {       // rows of global queries in this tile
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int qq = q0 + 16 * s + 4 * h + (j & 3) + 8 * (j >> 2);
-        if ((unsigned)(qq - g0) < (unsigned)ng) { pf[j] = (__bf16)0.f; gf[j] = (__bf16)0.f; }
+        if ((unsigned)(qq - g0) < (unsigned)ng) px[j] = (__bf16)0.f;
       }
     }
+    return px;
   };
-  // The global query rows against this wave's keys: Q_g / dO_g rows 0..7 (tile shape) and the 8-row image pair the
+  // P' (dropped -> 0; the 1 / keep_prob factor is applied to dV once, at the end) and dS = |x| (dP' - delta) as the B
+  // registers of a step; dl = the delta of the step's rows, dp8 = its dP registers
+  auto finish = [&](const bf16x8& px, const float (&dp8)[8], const float (&dl)[8], bf16x8& pf, bf16x8& gf) {
+    pf = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(s16x8, px), (s16x8)(short)0));   // bf16 >= 0 <=> its bits as int16 >= 0
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (float)px[j];
+      float t = fmaf(dp8[j], ik, -dl[j]);
+      t = x < 0.f ? -dl[j] : t;
+      gf[j] = (__bf16)(__builtin_fabsf(x) * t);
+    }
+  };
+  // a whole q tile: images qimg / doimg, P image (or strip) at plds, the rows' delta at drow (LDS floats)
+  auto tile = [&](const unsigned char* qimg, const unsigned char* doimg, const unsigned char* plds, const float* drow, int q0, bool strip) {
+    Frag<T> dof;
+    frag_from_tile(dof, doimg, lane);
+    f32x16 dp = {0};
+    dp = mma_rows(dof, vf, dp);          // dP [q x key]
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const bf16x8 px = x_regs(plds, s, q0, strip);
+      const f32x4 dlo = *reinterpret_cast<const f32x4*>(drow + 16 * s + 4 * h), dhi = *reinterpret_cast<const f32x4*>(drow + 16 * s + 8 + 4 * h);
+      float dp8[8], dl[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { dp8[j] = dp[8 * s + j]; dl[j] = j < 4 ? dlo[j] : dhi[j - 4]; }
+      bf16x8 pf, gf;
+      finish(px, dp8, dl, pf, gf);
+      step(qimg, doimg, s, pf, gf, true);
+    }
+  };
+  // The global query rows against this wave's keys: Q_g / dO_g rows 0..7 (tile shape) and the 8-row image the
   // global-row items of the dQ pass left for this key tile ([block 4][row 8][16 bytes]; rows past the last global token
-  // were not written: zeros here).  `area`: 3 KiB of this wave's LDS.
+  // were not written: zeros here).  `area`: 2.5 KiB of this wave's LDS.
   auto global_rows = [&](unsigned char* area) {
     const bf16x8 qg = buf16(rq, voff_qc, (unsigned)g0 * qs1b);
     const bf16x8 dog = buf16(rdo, voff_oc, (unsigned)g0 * os1b);
     const unsigned char* gp = ho_grow_base(p, n_tiles, bn) + (size_t)kb * kHoStrip + lane * 8;
     const bool gl = ((lane >> 1) & 7) < ng;
-    const bf16x4 gp4 = gl ? *reinterpret_cast<const bf16x4*>(gp) : z4, gs4 = gl ? *reinterpret_cast<const bf16x4*>(gp + 512) : z4;
+    const bf16x4 gp4 = gl ? *reinterpret_cast<const bf16x4*>(gp) : z4;
+    float dl[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { dl[j] = delta_bn[min(g0 + 4 * h + j, p.S - 1)]; dl[4 + j] = 0.f; }
     const int row = lane >> 3, ch = lane & 7;
     const int off = row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
     *reinterpret_cast<bf16x8*>(area + off) = qg;
     *reinterpret_cast<bf16x8*>(area + 1024 + off) = dog;
     *reinterpret_cast<bf16x4*>(area + 2048 + lane * 8) = gp4;
-    *reinterpret_cast<bf16x4*>(area + 2560 + lane * 8) = gs4;
     wave_lds_sync();
+    Frag<T> dogf;
+    {
+      const int rr = r & 7;
+      const unsigned char* drow = area + 1024 + rr * 128 + ((h ^ ((rr >> 1) & 1)) << 6);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) dogf.v[s] = *reinterpret_cast<const bf16x8*>(drow + s * 16);
+    }
+    f32x16 dp = {0};
+    dp = mma_rows(dogf, vf, dp);         // registers 0..3 = global rows 4 h + i
     const int boff = (2 * cb + (li & 1)) * 128 + (4 * h + (li >> 2)) * 16 + ((li >> 1) & 1) * 8;    // chunk li & 3 = keys 16 cb + 4 (li & 3) ..
-    step(area, area + 1024, 0, join(tr(area + 2048 + boff), z4), join(tr(area + 2560 + boff), z4), false);
+    const bf16x8 px = join(tr(area + 2048 + boff), z4);
+    float dp8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dp8[j] = j < 4 ? dp[j] : 0.f;
+    bf16x8 pf, gf;
+    finish(px, dp8, dl, pf, gf);
+    step(area, area + 1024, 0, pf, gf, false);
     wave_lds_sync();
   };
 
@@ -1286,14 +1350,14 @@ __global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const
     const int n_win = (min(k0wg + 127 + W, p.S - 1) >> 5) - t0w + 1;          // <= 8 (launcher)
     unsigned char* qwin = smem;
     unsigned char* dowin = smem + 8 * 4096;
-    unsigned char* area = smem + 16 * 4096 + wave * 4096;
-    bf16x8 pt[5][2], st[5][2];
+    float* dwin = reinterpret_cast<float*>(smem + 16 * 4096);
+    unsigned char* area = smem + 16 * 4096 + 1024 + wave * 3072;
+    bf16x8 pt[5][2];
 #pragma unroll
     for (int it = 0; it < 5; ++it)
       if (it < n_it) {
         const unsigned char* tp = band_tile(t0 + it);
         pt[it][0] = *reinterpret_cast<const bf16x8*>(tp); pt[it][1] = *reinterpret_cast<const bf16x8*>(tp + 1024);
-        st[it][0] = *reinterpret_cast<const bf16x8*>(tp + 2048); st[it][1] = *reinterpret_cast<const bf16x8*>(tp + 3072);
       }
     {
       const int tid = threadIdx.x, row = tid >> 3, ch = tid & 7;
@@ -1305,40 +1369,43 @@ __global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const
           wq[t] = buf16(rq, (unsigned)row * qs1b + ch * 16, (unsigned)(t0w + t) * 32 * qs1b);
           wd[t] = buf16(rdo, (unsigned)row * os1b + ch * 16, (unsigned)(t0w + t) * 32 * os1b);
         }
+      const float dv = delta_bn[min(t0w * 32 + tid, p.S - 1)];
 #pragma unroll
       for (int t = 0; t < 8; ++t)
         if (t < n_win) {
           *reinterpret_cast<bf16x8*>(qwin + t * 4096 + dst) = wq[t];
           *reinterpret_cast<bf16x8*>(dowin + t * 4096 + dst) = wd[t];
         }
+      HSTAMP(1);
+      dwin[tid] = dv;
     }
     __syncthreads();
+    HSTAMP(2);
     if (!live) return;
     if (ng > 0) global_rows(area);
+    HSTAMP(3);
 #pragma unroll
     for (int it = 0; it < 5; ++it)
       if (it < n_it) {
-        const int qb = t0 + it;
+        const int qb = t0 + it, ws = qb - t0w;
         *reinterpret_cast<bf16x8*>(area + lane * 16) = pt[it][0]; *reinterpret_cast<bf16x8*>(area + 1024 + lane * 16) = pt[it][1];
-        *reinterpret_cast<bf16x8*>(area + 2048 + lane * 16) = st[it][0]; *reinterpret_cast<bf16x8*>(area + 3072 + lane * 16) = st[it][1];
         wave_lds_sync();
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          bf16x8 pf, gf;
-          b_regs(area, area + 2048, s, qb * 32, false, pf, gf);
-          step(qwin + (qb - t0w) * 4096, dowin + (qb - t0w) * 4096, s, pf, gf, true);
-        }
+        tile(qwin + ws * 4096, dowin + ws * 4096, area, dwin + ws * 32, qb * 32, false);
         wave_lds_sync();
+        HSTAMP(4 + it);
       }
+    HSTAMP(12);
   } else {
     // ---- per-wave form: band key waves (WIN = false) and the global-key items ----
-    constexpr int kWave = 2 * 4096 + 2 * 2048;          // Q tile, dO tile, P' image, dS image
-    unsigned char* qlds = smem + wave * kWave;
+    unsigned char* qlds = smem + wave * kHoWaveLds;
     unsigned char* dolds = qlds + 4096;
     unsigned char* plds = dolds + 4096;
-    unsigned char* slds = plds + 2048;
-    // one q tile's operands: Q / dO rows in tile shape, the two images as they lie in memory
-    bf16x8 qt[4], dot[4], pt[2], st[2];
+    float* drow = reinterpret_cast<float*>(plds + 2048);
+    // one q tile's operands: Q / dO rows in tile shape, the image as it lies in memory, the rows' delta -- one tile ahead.
+    // (Two tiles ahead, in two register sets, was slower: 58 -> 66 us per call.  The pass is not waiting for single
+    // round trips; with more bytes in flight per wave the queues in front of L2 only get longer.)
+    bf16x8 qt[4], dot[4], pt[2];
+    float rc_d = 0.f;
     auto fetch = [&](int qb) {
       const unsigned q0 = (unsigned)qb * 32;
 #pragma unroll
@@ -1346,15 +1413,14 @@ __global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const
         qt[u] = buf16(rq, voff_qc, (q0 + 8 * u) * qs1b);
         dot[u] = buf16(rdo, voff_oc, (q0 + 8 * u) * os1b);
       }
-      if (split_item) {            // strip: 512 + 512 bytes, 8 per lane
-        const unsigned char* sp = ho_strip(p, n_tiles, bn, qb) + lane * 8;
-        const bf16x4 a = *reinterpret_cast<const bf16x4*>(sp), c = *reinterpret_cast<const bf16x4*>(sp + 512);
+      rc_d = delta_bn[min((int)q0 + r, p.S - 1)];
+      if (split_item) {            // strip: 512 bytes, 8 per lane
+        const bf16x4 a = *reinterpret_cast<const bf16x4*>(ho_strip(p, n_tiles, bn, qb) + lane * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { pt[0][j] = a[j]; st[0][j] = c[j]; }
+        for (int j = 0; j < 4; ++j) pt[0][j] = a[j];
       } else {
         const unsigned char* tp = band_tile(qb);
         pt[0] = *reinterpret_cast<const bf16x8*>(tp); pt[1] = *reinterpret_cast<const bf16x8*>(tp + 1024);
-        st[0] = *reinterpret_cast<const bf16x8*>(tp + 2048); st[1] = *reinterpret_cast<const bf16x8*>(tp + 3072);
       }
     };
     fetch(t0);
@@ -1365,24 +1431,18 @@ __global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const
       tile_to_lds(dolds, dot, lane);
       if (split_item) {
         *reinterpret_cast<bf16x4*>(plds + lane * 8) = bf16x4{pt[0][0], pt[0][1], pt[0][2], pt[0][3]};
-        *reinterpret_cast<bf16x4*>(slds + lane * 8) = bf16x4{st[0][0], st[0][1], st[0][2], st[0][3]};
       } else {
         *reinterpret_cast<bf16x8*>(plds + lane * 16) = pt[0]; *reinterpret_cast<bf16x8*>(plds + 1024 + lane * 16) = pt[1];
-        *reinterpret_cast<bf16x8*>(slds + lane * 16) = st[0]; *reinterpret_cast<bf16x8*>(slds + 1024 + lane * 16) = st[1];
       }
+      if (h == 0) drow[r] = rc_d;
       if (it + 1 < n_it) fetch(qb + 1);
       wave_lds_sync();
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 pf, gf;
-        b_regs(plds, slds, s, qb * 32, split_item, pf, gf);
-        step(qlds, dolds, s, pf, gf, true);
-      }
+      tile(qlds, dolds, plds, drow, qb * 32, split_item);
       wave_lds_sync();
     }
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { dk0[i] *= p.gscale; dk1[i] *= p.gscale; }
+  for (int i = 0; i < 16; ++i) { dk0[i] *= p.gscale; dk1[i] *= p.gscale; dv0[i] *= ik; dv1[i] *= ik; }
 
   // fp32 rows of the global keys: partial slot `chunk` (items) or n_chunks (band waves) of part_dkv
   const bool k_glob = ng > 0 && (unsigned)(k - g0) < (unsigned)ng;
@@ -1415,6 +1475,7 @@ __global__ __launch_bounds__(256, WIN ? 2 : 3) void attn_bwd_dkv_ho_kernel(const
     *reinterpret_cast<bf16x4*>(DK + d) = x; *reinterpret_cast<bf16x4*>(DK + 32 + d) = y;
     *reinterpret_cast<bf16x4*>(DV + d) = z; *reinterpret_cast<bf16x4*>(DV + 32 + d) = u;
   }
+  HSTAMP(13);
 }
 
 // ------------------------------------ launcher --------------------------------------------
@@ -1451,12 +1512,12 @@ static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
     if (win) {
       static bool granted = false;
       if (!granted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_ho_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_ho_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kHoWinLds);
         granted = true;
       }
-      hipLaunchKernelGGL(attn_bwd_dkv_ho_kernel<true>, grid_kv, dim3(256), 80 * 1024, st, p);
+      hipLaunchKernelGGL(attn_bwd_dkv_ho_kernel<true>, grid_kv, dim3(256), kHoWinLds, st, p);
     } else {
-      hipLaunchKernelGGL(attn_bwd_dkv_ho_kernel<false>, grid_kv, dim3(256), 4 * (2 * 4096 + 2 * 2048), st, p);
+      hipLaunchKernelGGL(attn_bwd_dkv_ho_kernel<false>, grid_kv, dim3(256), 4 * kHoWaveLds, st, p);
     }
   } else hipLaunchKernelGGL((attn_bwd_dkv_band_bf16_kernel<Rp, REL>), grid_kv, dim3(256), lds_b, st, p);
   if ((e = hipGetLastError()) != hipSuccess) return e;

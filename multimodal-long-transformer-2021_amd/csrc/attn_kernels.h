@@ -76,11 +76,11 @@ struct BwdParams {
   float* part_red;   // [B*N * ceil(S/128) * 4 waves, Rp*64 + Rp]  per-wave dE^T / dbias partials
   int n_band_blocks, n_chunks, chunk_tiles, n_gblk, n_split;
   int peel_gkeys;       // bit 0, dQ pass: the (<= 8) global keys outside a wave's band tiles as a peeled quarter-tile step; bit 1, dK/dV pass: the global query rows likewise
-  // P / dS hand-over (lean bf16 path): the dQ pass stores every tile's P' (dropout applied) and dS as bf16 and the
-  // dK/dV pass (attn_bwd_dkv_ho_kernel) contracts them with dO / Q instead of recomputing S, dP, the exponentials
-  // and the keep hashes.  Regions of `ho` (bytes): band tiles [B*N][n_tiles q blocks][ho_slots][P 2 KiB | dS 2 KiB],
-  // then global-key strips [B*N][n_tiles q blocks][P 512 | dS 512] (32 rows x 8 keys), then global-row tiles
-  // [B*N][n_tiles key blocks][P 512 | dS 512] (8 rows x 32 keys).  NULL = off.
+  // P hand-over (lean bf16 path, attn_bwd_band.hip): the dQ pass stores every tile's probabilities as bf16 (sign bit =
+  // dropped) and the dK/dV pass (attn_bwd_dkv_ho_kernel) rebuilds P' and dS from them instead of recomputing scores,
+  // exponentials, masks and keep hashes.  Regions of `ho` (bytes): band tiles [B*N][n_tiles q blocks][ho_slots][2 KiB],
+  // then global-key strips [B*N][n_tiles q blocks][512] (32 rows x 8 keys), then global-row tiles
+  // [B*N][n_tiles key blocks][512] (8 rows x 32 keys).  NULL = off.
   unsigned char* ho;
   int ho_slots;         // band key tiles per 32-row q block: 2 * ceil(radius / 32) + 1
   int dkv_slots;        // partial slots per (plane, global block) in part_dkv: n_chunks, + 1 with the hand-over (the

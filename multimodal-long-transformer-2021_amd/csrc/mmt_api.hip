@@ -116,7 +116,7 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
   pl.off_red = pl.off_pdkv + bn * pl.n_rowblk * (pl.n_chunks + 1) * (2 * 32 * 64);      // (+ 1: the hand-over's band slot)
   pl.off_ho = (pl.off_red + bn * ((d->S + 127) / 128) * 4 * (Rp * 64 + Rp) + 3) & ~(size_t)3;
   pl.ho_slots = handover_slots(d, dense);
-  const size_t ho_bytes = pl.ho_slots ? bn * n_tiles * ((size_t)pl.ho_slots * 4096 + 2048) : 0;
+  const size_t ho_bytes = pl.ho_slots ? bn * n_tiles * ((size_t)pl.ho_slots * 2048 + 1024) : 0;
   pl.bwd_ws = pl.off_ho * sizeof(float) + ho_bytes;
   return pl;
 }

@@ -161,6 +161,56 @@ def test_config3_shape_backward_against_oracle():
   assert worst < 3e-2
 
 
+# ---- the three forms of the dK/dV pass on the lean bf16 path ----
+DKV_FORMS = {'recompute': {'MMT_BWD_HANDOVER': '0'}, 'handover-wave': {'MMT_HO_WIN': '0'}, 'handover-window': {}}
+
+
+@pytest.mark.parametrize('form', list(DKV_FORMS))
+@pytest.mark.parametrize('cfg', [
+    dict(B=2, S=256, N=2, R=32, radius=16, g0=200, ng=8, m=12),
+    dict(B=2, S=300, N=2, R=32, radius=64, g0=251, ng=8, m=12, valid=[300, 211]),     # ragged, odd global start (two key tiles)
+    dict(B=1, S=700, N=2, R=32, radius=40, g0=100, ng=5, m=7),                        # radius not a tile multiple
+    dict(B=1, S=640, N=2, R=25, radius=64, g0=630, ng=3, m=12),                       # globals in the last tile
+    dict(B=1, S=520, N=2, R=0, radius=64, g0=0, ng=8),                                # no relative term
+    dict(B=1, S=700, N=2, R=32, radius=96, g0=333, ng=8, m=12),                       # 7 band tiles per block: per-wave form only
+    dict(B=1, S=600, N=2, R=32, radius=64, m=12),                                     # no global tokens
+    dict(B=2, S=64, N=1, R=9, radius=8, g0=10, ng=2, valid=[0, 64]),
+    dict(B=1, S=20, N=2, R=9, radius=4, g0=0, ng=1),
+    dict(B=1, S=96, N=1, R=32, radius=200, g0=40, ng=8, m=12),                        # radius beyond the sequence: no split items
+    dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),
+], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'm')))
+def test_dkv_pass_forms(cfg, form, monkeypatch):
+  """The dK/dV pass that recomputes S / dP / P (attn_bwd_dkv_band_bf16_kernel) and the two forms that read the dQ
+  pass's probabilities (attn_bwd_dkv_ho_kernel: per-wave tiles, workgroup window), each against the oracle."""
+  for k, v in DKV_FORMS[form].items():
+    monkeypatch.setenv(k, v)
+  run_bwd(dtype=torch.bfloat16, dense=False, **cfg)
+
+
+def test_dkv_pass_forms_agree_under_dropout(monkeypatch):
+  """Same seed: the hand-over carries the dQ pass's keep decisions (sign bit of the stored probability), the
+  recomputing pass regenerates them -- dK / dV agree to bf16 rounding."""
+  import mmt_amd
+  B, S, N, R = 2, 1024, 2, 32
+  q, k, v, emb, bias = (torch.from_numpy(bf16_round(x)).cuda().bfloat16() for x in attention_inputs(B, S, N, R, seed=21))
+  dout = torch.from_numpy(bf16_round(np.random.default_rng(5).standard_normal(q.shape).astype(np.float32))).cuda().bfloat16()
+  pat = mmt_amd.AttentionPattern(local_radius=64, global_start=771, n_global=8, id_mode=1, max_dist=12)
+  kw = dict(pattern=pat, dropout_p=0.25, dropout_seed=77)
+  out, lse = mmt_amd.relative_attention_forward(q, k, v, emb, bias, **kw)
+  res = {}
+  for form, env in DKV_FORMS.items():
+    for kk in ('MMT_BWD_HANDOVER', 'MMT_HO_WIN'):
+      monkeypatch.delenv(kk, raising=False)
+    for kk, vv in env.items():
+      monkeypatch.setenv(kk, vv)
+    res[form] = [g.float().cpu().numpy() for g in mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, out, lse, **kw)]
+  for form in ('handover-wave', 'handover-window'):
+    for a, b in zip(res['recompute'], res[form]):
+      assert np.abs(a - b).max() <= 3e-2 * max(1.0, np.abs(a).max()), form
+  for a, b in zip(res['handover-wave'], res['handover-window']):      # same arithmetic, different staging
+    assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(a).max())
+
+
 # ---- attention-probability dropout: the in-kernel keep mask against its restatement (oracle.dropout_keep_mask) ----
 @pytest.mark.parametrize('path', ['lean_bf16', 'general_f32', 'dense_f32'])
 def test_dropout_mask_matches_oracle_forward_and_backward(path):
