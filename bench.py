@@ -288,6 +288,9 @@ def main():
     else:
       step_fn = attn_fwd
 
+  if mode == 'train_step' and step_info.get('step_launch', '').startswith('HIP graph'):
+    for _ in range(4):       # set-up, not warm-up: three eager steps and the one that records the graph (mmt_amd/graphed.py)
+      step_fn()
   for _ in range(args.warmup):
     step_fn()
   barrier()
@@ -296,6 +299,7 @@ def main():
     step_fn()
   barrier()
   dt = time.perf_counter() - t0
+  getattr(step_fn, 'close', lambda: None)()      # back to host-side step scalars for the per-call measurements below
   if world > 1:
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MMT_ABI_VERSION 2
+#define MMT_ABI_VERSION 3
 
 enum {
   MMT_OK = 0,
@@ -98,6 +98,18 @@ int mmt_abi_version(void);
 
 /* Message of the last failure on this thread ("" if none).  Never NULL. */
 const char* mmt_last_error(void);
+
+/* Per-step scalars that live in DEVICE memory, for callers that record a train step once as a HIP graph and replay it
+ * (kernel arguments are frozen in a graph; these are read by the kernels when they start):
+ *   dropout_epoch : one uint64.  Every kernel of this library that draws a dropout mask (attention probabilities,
+ *                   mmt_layer.h residual blocks and embedding assembly) adds *dropout_epoch to its descriptor's
+ *                   dropout_seed -- forward and backward alike, so a backward still regenerates its forward's mask.
+ *   adamw_hyper   : three floats {lr, bias_correction1, bias_correction2} that mmt_adamw_step uses INSTEAD of the
+ *                   fields of its descriptor.
+ * Either may be NULL (= off, the default).  Process-wide setting, read at every launch; the memory must stay valid
+ * while launches (or graph replays) that captured it can run.  Replaces nothing in the reference: its train step
+ * (src/tasks/pretraining.py:224-298) is a tf.function whose step-dependent values are tf.Variables for the same reason. */
+int mmt_set_step_scalars(const uint64_t* dropout_epoch, const float* adamw_hyper);
 
 /* Bytes of scratch mmt_attn_fwd / mmt_attn_bwd need for this descriptor (the larger of
  * the two).  Host-only computation. */

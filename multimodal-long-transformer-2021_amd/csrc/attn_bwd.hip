@@ -81,7 +81,7 @@ __device__ __forceinline__ void pair_mask_col(const P& p, int b, int valid_len, 
 template <typename T, typename P>
 __device__ __forceinline__ float drop_factor(const P& p, int bn, int q, int k) {
   if (!p.drop_thresh) return 1.f;
-  const uint32_t bits = drop_bits16(drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q), (uint32_t)k);
+  const uint32_t bits = drop_bits16(drop_row_base(effective_seed(p.seed_lo, p.seed_hi, p.epoch).lo, effective_seed(p.seed_lo, p.seed_hi, p.epoch).hi, (uint32_t)bn, (uint32_t)q), (uint32_t)k);
   return bits >= p.drop_thresh ? p.inv_keep : 0.f;
 }
 

@@ -271,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   const float* trow = tab + r * kTStride(Rp);
   float* dtrow = dtab + r * dstride;
   const int trow_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)(tab + r * kTStride(Rp));
-  const uint32_t drop_base = drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q);
+  const SeedPair sd = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
+  const uint32_t drop_base = drop_row_base(sd.lo, sd.hi, (uint32_t)bn, (uint32_t)q);
   // REL == 2: this lane's query on the patch grid, LDS addresses of the look-up table and of the lane's dRel row
   const int xq2 = (int)__umulhi((unsigned)q, p.pat.magicP), yq2 = q - xq2 * p.pat.P;
   const int lut_addr = lds_addr(lut), dtrow_addr = lds_addr(dtrow);
@@ -831,7 +832,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_band_bf16_kernel(const Bw
 
   f32x16 dk0 = {0}, dk1 = {0}, dv0 = {0}, dv1 = {0};
   const int tab_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)tab;
-  const uint32_t bn_seed = mix32(p.seed_lo ^ ((uint32_t)bn * 0x9E3779B9u)) + p.seed_hi;
+  const SeedPair sd = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
+  const uint32_t bn_seed = mix32(sd.lo ^ ((uint32_t)bn * 0x9E3779B9u)) + sd.hi;
   const uint32_t drop_kterm = (uint32_t)(k >> 1) * kDropPairMul, drop_ksh = (k & 1) ? 16u : 0u;   // this lane's key
 
   if (peel) {

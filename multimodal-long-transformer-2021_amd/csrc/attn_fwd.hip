@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const FwdParams p) {
     if (p.drop_thresh) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const uint32_t bits = drop_bits16(drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q),
+        const uint32_t bits = drop_bits16(drop_row_base(effective_seed(p.seed_lo, p.seed_hi, p.epoch).lo, effective_seed(p.seed_lo, p.seed_hi, p.epoch).hi, (uint32_t)bn, (uint32_t)q),
                                           (uint32_t)(k0 + kap(i, h)));
         pr[i] = bits >= p.drop_thresh ? pr[i] * p.inv_keep : 0.f;
       }

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256, (Rp == 64 && REL == 2) ? 2 : 3) void attn_fwd_
   const float* trow = tab + r * kTStride(Rp);
   const int trow_addr = (int)(unsigned)(size_t)(__attribute__((address_space(3))) float*)(tab + r * kTStride(Rp));
   const bool qblk_valid = q0 + 31 < valid_len, qblk_pad = q0 >= valid_len, qblk_in = q0 + 31 < p.S;
-  const uint32_t drop_base = drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q);
+  const SeedPair sd = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
+  const uint32_t drop_base = drop_row_base(sd.lo, sd.hi, (uint32_t)bn, (uint32_t)q);
   // REL == 2: this lane's query on the patch grid, and the LDS address of the look-up table
   const int xq2 = (int)__umulhi((unsigned)q, p.pat.magicP), yq2 = q - xq2 * p.pat.P;
   const int lut_addr = lds_addr(lut);

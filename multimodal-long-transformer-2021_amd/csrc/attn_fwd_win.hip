@@ -178,6 +178,7 @@ __device__ __forceinline__ void fwd_rows_body(const FwdParams& p, unsigned char*
   }
   __syncthreads();
   // this lane's four queries: 4h + i
+  const SeedPair sdr = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
   bool qvalid[4], qin[4];
   uint32_t dbase[4];
 #pragma unroll
@@ -185,7 +186,7 @@ __device__ __forceinline__ void fwd_rows_body(const FwdParams& p, unsigned char*
     const int qi = 4 * h + i;
     qin[i] = qi < n_q;
     qvalid[i] = qg0 + qi < valid_len;
-    dbase[i] = drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)(qg0 + qi));
+    dbase[i] = drop_row_base(sdr.lo, sdr.hi, (uint32_t)bn, (uint32_t)(qg0 + qi));
   }
   const uint32_t t16 = p.drop_thresh;
 
@@ -519,7 +520,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_win_bf16_kernel(const FwdPara
   const int trow_addr = (int)lds_u32(trow);
   const bool q_ok = q < p.S;
   const bool qblk_valid = q0 + 31 < valid_len, qblk_pad = q0 >= valid_len, qblk_in = q0 + 31 < p.S;
-  const uint32_t drop_base = drop_row_base(p.seed_lo, p.seed_hi, (uint32_t)bn, (uint32_t)q);
+  const SeedPair sd = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
+  const uint32_t drop_base = drop_row_base(sd.lo, sd.hi, (uint32_t)bn, (uint32_t)q);
   const uint32_t t16 = p.drop_thresh;
 
   // the block's band tiles b0 .. b1; wave A takes the first two (after the peeled global keys), wave B the rest

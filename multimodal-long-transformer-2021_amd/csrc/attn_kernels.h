@@ -23,6 +23,7 @@ struct FwdParams {
   // dropout
   uint32_t drop_thresh;  // 16-bit threshold: keep iff bits16 >= thresh; 0 disables
   uint32_t seed_lo, seed_hi;
+  const unsigned long long* epoch;      // device-resident addend of the seed (mmt_set_step_scalars) or NULL
   float inv_keep;
   // kRows
   float* part_o;
@@ -65,6 +66,7 @@ struct BwdParams {
   int lean2d;                         // 2-D ids on the lean path (Rp already narrowed to the ids that can contribute)
   int skip_global;                    // band items leave global rows / keys to the split items
   uint32_t drop_thresh, seed_lo, seed_hi;
+  const unsigned long long* epoch;      // as FwdParams
   float inv_keep;
   // workspace
   float* delta;      // [B,N,S]       rowsum(dO * O)

@@ -31,6 +31,7 @@ struct EmbedParams {
   int S, H, vocab, seg_vocab, patch_start, n_patch;
   float eps, inv_keep;
   uint32_t thresh16, seed_lo, seed_hi;
+  const unsigned long long* epoch;     // device-resident addend of the seed (mmt_set_step_scalars) or NULL
   const int *word_ids, *seg_ids, *order, *sorted_ids;   // sorted_ids[i] = word_ids[order[i]]
   const float *word_table, *seg_table, *pos_table, *gamma, *beta, *patch_bias;
   const void* patch;
@@ -48,6 +49,7 @@ struct EmbedParams {
 
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
+  const SeedPair sd = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.H >> 3;
   const float invH = 1.f / (float)p.H;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float w = (v[j][i] - mean) * rstd * g[i] + bt[i];
-        if (p.thresh16) w = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? w * p.inv_keep : 0.f;
+        if (p.thresh16) w = drop_bits16(sd.lo, sd.hi, (uint64_t)(off + i)) >= p.thresh16 ? w * p.inv_keep : 0.f;
         y[i] = w;
       }
       if (sg_ok) {
@@ -120,6 +122,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
 // their piece [i, end): end = first position with another id, or the next cut.
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedParams p) {
+  const SeedPair sd = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
   __shared__ float red[4][64 * NCH * 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.H >> 3;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedParams p) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             float v = t[u][j][i];
-            if (p.thresh16) v = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? v * p.inv_keep : 0.f;
+            if (p.thresh16) v = drop_bits16(sd.lo, sd.hi, (uint64_t)(off + i)) >= p.thresh16 ? v * p.inv_keep : 0.f;
             tsum[j][i] += v;
           }
         }
@@ -328,6 +331,7 @@ void fill_embed(mmt::EmbedParams& p, const mmt_embed_desc* d) {
   if (p.thresh16) {
     p.inv_keep = mmt::dropout_inv_keep(p.thresh16);
     p.seed_lo = (uint32_t)d->dropout_seed; p.seed_hi = (uint32_t)(d->dropout_seed >> 32);
+    p.epoch = mmt::g_dropout_epoch;
   }
 }
 

@@ -25,6 +25,7 @@ struct LayerParams {
   int H;
   float eps, inv_keep;
   uint32_t thresh16, seed_lo, seed_hi;
+  const unsigned long long* epoch;     // device-resident addend of the seed (mmt_set_step_scalars) or NULL
   const void *a, *b, *c;          // inputs (meaning per kernel)
   const float *p0, *p1, *p2;      // fp32 parameters / statistics
   const float *mean, *rstd;
@@ -40,6 +41,7 @@ struct LayerParams {
 // =============================================================================================
 template <typename T, int W, int NCH, bool RESID, bool HAS_LN>
 __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const LayerParams p) {
+  const SeedPair sd = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.H / W;
   const float invH = 1.f / (float)p.H;
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const LayerParams p) 
 #pragma unroll
           for (int i = 0; i < W; ++i) {
             float t = o[i] + bs[i];
-            if (p.thresh16) t = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
+            if (p.thresh16) t = drop_bits16(sd.lo, sd.hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
             v[j][i] = x[i] + t;
             if (sizeof(T) == 2) v[j][i] = (float)(__bf16)v[j][i];      // LayerNorm sees the stored (rounded) x_new
           }
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const LayerParams p) 
 // =============================================================================================
 template <typename T, int W, int NCH, bool RESID, bool HAS_LN>
 __global__ __launch_bounds__(256, (W * NCH <= 12 ? 4 : 1)) void resid_ln_bwd_kernel(const LayerParams p) {
+  const SeedPair sd = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
   __shared__ float red[4][64 * NCH * W];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.H / W;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256, (W * NCH <= 12 ? 4 : 1)) void resid_ln_bwd_ker
 #pragma unroll
           for (int i = 0; i < W; ++i) {
             float t = dx[i];
-            if (p.thresh16) t = drop_bits16(p.seed_lo, p.seed_hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
+            if (p.thresh16) t = drop_bits16(sd.lo, sd.hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
             d_o[i] = t;
             acc_b[j][i] += t;
           }
@@ -435,8 +438,14 @@ struct AdamwParams {
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ prm, float* __restrict__ grd,
                                                     float* __restrict__ m1, float* __restrict__ m2,
                                                     __bf16* __restrict__ shadow, const float* __restrict__ chunk_wd,
-                                                    const float* __restrict__ grad_scale, long n_chunks, AdamwParams a) {
+                                                    const float* __restrict__ grad_scale, long n_chunks, AdamwParams a,
+                                                    const float* __restrict__ hyper) {
   const float gs = grad_scale ? *grad_scale : 1.f;
+  if (hyper) {          // device-resident {lr, bias_correction1, bias_correction2} (mmt_set_step_scalars)
+    a.lr = hyper[0];
+    a.inv_bc1 = 1.f / hyper[1];
+    a.inv_sqrt_bc2 = 1.f / sqrtf(hyper[2]);
+  }
   // two chunks per iteration: eight 16-byte loads in flight per thread before the first store
   for (long c0 = blockIdx.x; c0 < n_chunks; c0 += 2L * gridDim.x) {
     const long c1 = c0 + gridDim.x;
@@ -512,6 +521,7 @@ void fill(mmt::LayerParams& p, const mmt_rows_desc* d) {
     p.thresh16 = mmt::dropout_thresh16(d->dropout_p);
     p.inv_keep = mmt::dropout_inv_keep(p.thresh16);          // exact keep probability of the 16-bit test
     p.seed_lo = (uint32_t)d->dropout_seed; p.seed_hi = (uint32_t)(d->dropout_seed >> 32);
+    p.epoch = mmt::g_dropout_epoch;
   }
 }
 
@@ -689,7 +699,7 @@ int mmt_adamw_step(const mmt_adamw_desc* d, float* param, float* grad, float* ex
   const long n_chunks = d->n >> 10;
   const long blocks = n_chunks < 8192 ? n_chunks : 8192;
   hipLaunchKernelGGL(mmt::adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, (__bf16*)param_bf16, chunk_wd, grad_scale, n_chunks, a);
+                     exp_avg_sq, (__bf16*)param_bf16, chunk_wd, grad_scale, n_chunks, a, mmt::g_adamw_hyper);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_adamw_step: %s", hipGetErrorString(e));
 }

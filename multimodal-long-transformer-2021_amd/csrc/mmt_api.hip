@@ -27,6 +27,11 @@ int fail(int code, const char* fmt, ...) {
 }
 }  // namespace mmt
 
+namespace mmt {
+const unsigned long long* g_dropout_epoch = nullptr;
+const float* g_adamw_hyper = nullptr;
+}
+
 namespace {
 using mmt::fail;
 
@@ -154,6 +159,7 @@ void fill_common(mmt::FwdParams& p, const mmt_attn_desc* d) {
     p.inv_keep = 65536.f / (65536.f - (float)p.drop_thresh);   // exact keep probability of the 16-bit test
     p.seed_lo = (uint32_t)d->dropout_seed;
     p.seed_hi = (uint32_t)(d->dropout_seed >> 32);
+    p.epoch = mmt::g_dropout_epoch;
   }
 }
 
@@ -162,6 +168,12 @@ void fill_common(mmt::FwdParams& p, const mmt_attn_desc* d) {
 extern "C" {
 
 int mmt_abi_version(void) { return MMT_ABI_VERSION; }
+
+int mmt_set_step_scalars(const uint64_t* dropout_epoch, const float* adamw_hyper) {
+  mmt::g_dropout_epoch = reinterpret_cast<const unsigned long long*>(dropout_epoch);
+  mmt::g_adamw_hyper = adamw_hyper;
+  return MMT_OK;
+}
 
 const char* mmt_last_error(void) { return g_err; }
 
@@ -277,7 +289,7 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   p.pat = f.pat;
   if (desc->R == 0) { p.pat.id_mode = 0; p.rel_ids = nullptr; }
   p.perm_1d = (!dense && p.pat.id_mode == MMT_IDS_1D && desc->R >= 2 * p.pat.m + 1) ? 1 : 0;
-  p.drop_thresh = f.drop_thresh; p.seed_lo = f.seed_lo; p.seed_hi = f.seed_hi; p.inv_keep = f.inv_keep;
+  p.drop_thresh = f.drop_thresh; p.seed_lo = f.seed_lo; p.seed_hi = f.seed_hi; p.inv_keep = f.inv_keep; p.epoch = f.epoch;
   if (desc->dtype == MMT_BF16) {
     if (const int w2 = lean2d_width(p.pat, desc->R, dense)) {      // lean 2-D path: the kernels run at the narrowed table width
       p.lean2d = 1;

@@ -104,6 +104,16 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 // column spread, neighbour correlations < 0.003) match the two-round mixer's.  The hash is the biggest single
 // item of a one-id tile's VALU work, and its 32-bit multiplies run at a quarter of the full rate.
 constexpr uint32_t kDropPairMul = 0xC2B2AE35u;
+// the dropout seed a kernel works with: the descriptor's, plus the device-resident epoch when one is set
+// (mmt_set_step_scalars; one scalar load per wave)
+struct SeedPair { uint32_t lo, hi; };
+__device__ __forceinline__ SeedPair effective_seed(uint32_t lo, uint32_t hi, const unsigned long long* epoch) {
+  if (epoch) {
+    const unsigned long long s = (((unsigned long long)hi << 32) | lo) + *epoch;
+    lo = (uint32_t)s; hi = (uint32_t)(s >> 32);
+  }
+  return SeedPair{lo, hi};
+}
 __host__ __device__ __forceinline__ uint32_t drop_row_base(uint32_t seed_lo, uint32_t seed_hi,
                                                            uint32_t bn, uint32_t q) {
   return mix32(seed_lo ^ (bn * 0x9E3779B9u)) + seed_hi + q * 0x85EBCA6Bu;

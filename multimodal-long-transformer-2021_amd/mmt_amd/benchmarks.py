@@ -5,7 +5,9 @@ from __future__ import annotations
 
 import torch
 
-from . import configs, distribute, optimization, tasks
+import os
+
+from . import configs, distribute, graphed, optimization, tasks
 
 
 def _exchanging(world: int) -> bool:
@@ -21,7 +23,9 @@ def _exchange_label(world: int, bucket_mb: float) -> str:
   return f'{name}, bucketed ({bucket_mb:.0f} MB) SUM all-reduce overlapped with backward'
 
 
-def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.bfloat16):
+def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.bfloat16, graph=None):
+  """`graph`: replay the step as a HIP graph after three eager steps (`graphed.GraphedTrainStep`); None = the
+  MMT_STEP_GRAPH switch (default on, bf16 only)."""
   exp = configs.get_exp_config('mmt/pretraining')
   P = cfg.get('P', 63)          # patches per image row (image side 16 P)
   exp.override({
@@ -51,20 +55,34 @@ def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.
   data = task.build_inputs(exp.task.train_data, device=device, rank=rank, batch_size=cfg['B'])
   batch = next(data)       # inputs resident in HBM before the timed region
   state = {'step': 0}
+  if graph is None:
+    graph = os.environ.get('MMT_STEP_GRAPH', '1') != '0'
+  graph = bool(graph) and dtype == torch.bfloat16 and hasattr(optimizer, 'slabs')
 
-  def step():
-    optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, state['step']))
-    state['step'] += 1
-    return task.train_step(batch, model, optimizer, reducer=reducer, clip_norm=opt_cfg.gradient_clip_norm,
-                           step=state['step'])
+  if graph:
+    graphed_step = graphed.GraphedTrainStep(task, model, optimizer, reducer, opt_cfg, clip_norm=opt_cfg.gradient_clip_norm)
 
+    def step():
+      state['step'] += 1
+      return graphed_step(batch, state['step'])
+    step.close = graphed_step.close
+  else:
+    def step():
+      optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, state['step']))
+      state['step'] += 1
+      return task.train_step(batch, model, optimizer, reducer=reducer, clip_norm=opt_cfg.gradient_clip_norm,
+                             step=state['step'])
+    step.close = lambda: None
+
+  step.optimizer, step.model = optimizer, model
   n_params = sum(p.numel() for p in model.parameters())
   d = exp.task.train_data
   info = {'model': 'MmtPretrainingModel (12 layers, hidden 768, 12 heads, intermediate 3072), mlm+itm heads',
           'params': n_params, 'optimizer': 'AdamW (fused flat step, bf16 shadow weights) + polynomial lr, clip 1.0',
           'dropout': 0.1, 'mlm_max_selections_per_seq': d.mlm_max_selections_per_seq,
           'mpp_max_selections_per_seq': d.mpp_max_selections_per_seq,
-          'grad_allreduce': _exchange_label(world, strategy.bucket_bytes / (1 << 20)), 'grad_reduce': reduce}
+          'grad_allreduce': _exchange_label(world, strategy.bucket_bytes / (1 << 20)), 'grad_reduce': reduce,
+          'step_launch': 'HIP graph replay (recorded after 3 eager steps)' if graph else 'eager (one launch per kernel)'}
   return step, info
 
 

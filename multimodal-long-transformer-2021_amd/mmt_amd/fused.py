@@ -13,7 +13,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, step_scalars
 
 # Dropout seeds are a pure function of (train step, micro step, data-parallel rank, index of the
 # dropout site within the forward pass): replicas draw different masks for their shards and a run
@@ -23,10 +23,12 @@ _seed_state = {'base': 0, 'n': 0}
 
 
 def set_seed_stream(step: int, micro_step: int = 0, rank: int = 0) -> None:
-  """Called by the tasks' train_step before every micro-step's forward pass."""
-  _seed_state['base'] = ((int(step) * 0x9E3779B97F4A7C15) ^ (int(micro_step) * 0xC2B2AE3D27D4EB4F)
-                         ^ ((int(rank) + 1) * 0x165667B19E3779F9)) & ((1 << 63) - 1)
+  """Called by the tasks' train_step before every micro-step's forward pass.  The step's share of the seeds (its
+  "epoch") is added where the descriptors are filled in -- or by the kernels themselves when it lives in device
+  memory (`step_scalars`) -- so the seeds handed around on the host do not depend on the step."""
+  _seed_state['base'] = ((int(micro_step) * 0xC2B2AE3D27D4EB4F) ^ ((int(rank) + 1) * 0x165667B19E3779F9)) & ((1 << 63) - 1)
   _seed_state['n'] = 0
+  step_scalars.set_step(step)
 
 
 def next_seed(base: int = 0) -> int:
@@ -46,7 +48,7 @@ def _desc(x2d: torch.Tensor, eps=1e-12, p=0.0, seed=0) -> _lib.RowsDesc:
     d.dtype = _lib.MMT_BF16
   else:
     raise TypeError(f'fused layer ops support float32 and bfloat16, got {x2d.dtype}')
-  d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), int(seed) & ((1 << 64) - 1)
+  d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), (int(seed) + step_scalars.host_epoch()) & ((1 << 64) - 1)
   return d
 
 
@@ -719,7 +721,7 @@ class _EmbedAssembleFn(torch.autograd.Function):
     d = _lib.EmbedDesc()
     d.rows, d.S, d.H, d.dtype = B * S, S, H, _dtype_code(out_dtype)
     d.vocab, d.seg_vocab, d.patch_start, d.n_patch = V, st.shape[0], int(patch_start), n_patch
-    d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), int(seed) & ((1 << 64) - 1)
+    d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), (int(seed) + step_scalars.host_epoch()) & ((1 << 64) - 1)
     out = torch.empty((B, S, H), dtype=out_dtype, device=word_table.device)
     mean = torch.empty(B * S, dtype=torch.float32, device=out.device)
     rstd = torch.empty_like(mean)

@@ -18,7 +18,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, step_scalars
 
 
 @dataclasses.dataclass(frozen=True)
@@ -172,7 +172,7 @@ def _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_bef
   d.mask_value = float(mask_value)
   d.flags = _lib.MMT_FLAG_SCALE_BEFORE_ADD if scale_before_add else 0
   d.dropout_p = float(dropout_p)
-  d.dropout_seed = int(dropout_seed) & ((1 << 64) - 1)
+  d.dropout_seed = (int(dropout_seed) + step_scalars.host_epoch()) & ((1 << 64) - 1)
   d.mask = (pattern or AttentionPattern(id_mode=_lib.MMT_IDS_NONE)).to_desc(valid_len, q.device)
   return d
 

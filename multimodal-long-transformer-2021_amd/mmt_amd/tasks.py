@@ -9,7 +9,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import configs, fused, gemm_tuning, input_utils, layers, models
+from . import step_scalars, configs, fused, gemm_tuning, input_utils, layers, models
 
 _TASKS = {}
 
@@ -138,6 +138,7 @@ class _TaskBase:
       optimizer.step(grad_scale=scale)
     else:
       optimizer.step()
+    step_scalars.set_step(0)          # calls outside a train step take their dropout seeds as given
     return {self.loss: all_loss}
 
   @torch.no_grad()

@@ -13,7 +13,7 @@ import time
 
 import torch
 
-from . import checkpoint, configs, distribute, optimization, tasks
+from . import checkpoint, configs, distribute, graphed, optimization, tasks
 
 
 def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, device=None,
@@ -58,10 +58,20 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
     # `task.build_metrics()` objects, updated on the device inside every step (process_metrics, pretraining.py:297);
     # read -- one all-reduce + one host copy each -- only on logging steps, then reset like orbit's summary loop
     train_metrics = task.build_metrics(training=True)
+    # the step as a HIP graph (recorded after three eager steps, graphed.py) when everything it touches has a fixed
+    # address: flat optimizer on the GPU, bf16 compute; MMT_STEP_GRAPH=0 keeps every step eager
+    graphed_step = None
+    if (os.environ.get('MMT_STEP_GRAPH', '1') != '0' and hasattr(optimizer, 'slabs')
+        and task.compute_dtype == torch.bfloat16):
+      graphed_step = graphed.GraphedTrainStep(task, model, optimizer, reducer, opt_cfg, metrics=train_metrics,
+                                              clip_norm=opt_cfg.gradient_clip_norm)
     for step in range(start, steps):
-      optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, step))
-      out = task.train_step(next(data), model, optimizer, metrics=train_metrics, reducer=reducer,
-                            clip_norm=opt_cfg.gradient_clip_norm, step=step + 1)
+      if graphed_step is not None:
+        out = graphed_step(next(data), step + 1)
+      else:
+        optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, step))
+        out = task.train_step(next(data), model, optimizer, metrics=train_metrics, reducer=reducer,
+                              clip_norm=opt_cfg.gradient_clip_norm, step=step + 1)
       if step % log_every == 0 or step == steps - 1:
         loss = float(out[task.loss])
         logs.append({'step': step, 'loss': loss, 'elapsed_s': time.perf_counter() - t0,
@@ -73,6 +83,8 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
         save(step + 1)
     if steps > start:
       save(steps)
+    if graphed_step is not None:
+      graphed_step.close()
   if 'eval' in mode:
     vdata = task.build_inputs(params.task.validation_data, device=device, rank=strategy.rank)
     eval_metrics = task.build_metrics(training=False)

@@ -25,8 +25,8 @@ def test_header_symbols_are_exported(lib):
   L = lib.lib()
   for name in declared:
     assert hasattr(L, name), name
-  assert L.mmt_abi_version() == 2
-  assert int(re.search(r'#define MMT_ABI_VERSION (\d+)', header).group(1)) == 2
+  assert L.mmt_abi_version() == 3
+  assert int(re.search(r'#define MMT_ABI_VERSION (\d+)', header).group(1)) == 3
 
 
 def test_struct_layout_matches_header(lib):

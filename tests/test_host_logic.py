@@ -225,15 +225,16 @@ def test_stale_bf16_shadow_is_resynchronised_after_a_master_write():
 
 
 def test_dropout_seed_stream_depends_on_step_micro_step_and_rank():
-  from mmt_amd import fused
-  def draw(step, micro, rank, n=3):
+  from mmt_amd import fused, step_scalars
+  def draw(step, micro, rank, n=3):       # the seeds the descriptors carry: host seed + the step's epoch
     fused.set_seed_stream(step, micro, rank)
-    return [fused.next_seed(0) for _ in range(n)]
+    return [(fused.next_seed(0) + step_scalars.host_epoch()) % (1 << 64) for _ in range(n)]
   a = draw(5, 0, 0)
   assert a == draw(5, 0, 0)                          # resumable: a pure function of its arguments
   assert len(set(a)) == 3
   for other in (draw(6, 0, 0), draw(5, 1, 0), draw(5, 0, 1)):
     assert not set(a) & set(other)
+  step_scalars.set_step(0)
 
 
 def test_gradient_reduce_mode_follows_the_task_config():
@@ -268,3 +269,19 @@ def test_attention_pattern_normalizes_listed_global_sets():
     P(global_index=(-1, 4)).normalized()
   with pytest.raises(ValueError):
     scat.to_desc(None)                      # a listed set needs the device its index list lives on
+
+
+def test_step_scalars_host_side():
+  """The step's share of a dropout seed (its epoch) is a pure function of the step, is what the descriptors add on the
+  host, and is left at zero after a train step so that explicit seeds outside one are taken as given."""
+  from mmt_amd import fused, step_scalars
+  assert step_scalars.epoch_of(0) == 0
+  assert step_scalars.epoch_of(3) == (3 * 0x9E3779B97F4A7C15) % (1 << 64)
+  fused.set_seed_stream(7, 1, 2)
+  a = fused.next_seed(0)
+  assert step_scalars.host_epoch() == step_scalars.epoch_of(7)
+  fused.set_seed_stream(8, 1, 2)
+  assert fused.next_seed(0) == a                     # the seeds handed around on the host do not depend on the step
+  assert step_scalars.host_epoch() == step_scalars.epoch_of(8)
+  step_scalars.set_step(0)
+  assert step_scalars.host_epoch() == 0 and not step_scalars.device_active()
