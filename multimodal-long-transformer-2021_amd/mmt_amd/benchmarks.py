@@ -25,7 +25,8 @@ def _exchange_label(world: int, bucket_mb: float) -> str:
 
 def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.bfloat16, graph=None):
   """`graph`: replay the step as a HIP graph after three eager steps (`graphed.GraphedTrainStep`); None = the
-  MMT_STEP_GRAPH switch (default on, bf16 only)."""
+  MMT_STEP_GRAPH switch: unset = on for a single-process run, off when gradients are exchanged (the capture of the RCCL
+  all-reduces is exercised with one rank only -- MMT_FORCE_DIST=1 MMT_STEP_GRAPH=1 -- not between devices); bf16 only."""
   exp = configs.get_exp_config('mmt/pretraining')
   P = cfg.get('P', 63)          # patches per image row (image side 16 P)
   exp.override({
@@ -55,8 +56,7 @@ def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.
   data = task.build_inputs(exp.task.train_data, device=device, rank=rank, batch_size=cfg['B'])
   batch = next(data)       # inputs resident in HBM before the timed region
   state = {'step': 0}
-  if graph is None:
-    graph = os.environ.get('MMT_STEP_GRAPH', '1') != '0'
+XX
   graph = bool(graph) and dtype == torch.bfloat16 and hasattr(optimizer, 'slabs')
 
   if graph:

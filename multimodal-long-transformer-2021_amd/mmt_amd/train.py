@@ -59,9 +59,10 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
     # read -- one all-reduce + one host copy each -- only on logging steps, then reset like orbit's summary loop
     train_metrics = task.build_metrics(training=True)
     # the step as a HIP graph (recorded after three eager steps, graphed.py) when everything it touches has a fixed
-    # address: flat optimizer on the GPU, bf16 compute; MMT_STEP_GRAPH=0 keeps every step eager
+    # address: flat optimizer on the GPU, bf16 compute.  MMT_STEP_GRAPH: unset = on with one replica, 0 / 1 = off / on
     graphed_step = None
-    if (os.environ.get('MMT_STEP_GRAPH', '1') != '0' and hasattr(optimizer, 'slabs')
+    env = os.environ.get('MMT_STEP_GRAPH')
+    if ((strategy.num_replicas_in_sync == 1 if env is None else env != '0') and hasattr(optimizer, 'slabs')
         and task.compute_dtype == torch.bfloat16):
       graphed_step = graphed.GraphedTrainStep(task, model, optimizer, reducer, opt_cfg, metrics=train_metrics,
                                               clip_norm=opt_cfg.gradient_clip_norm)
