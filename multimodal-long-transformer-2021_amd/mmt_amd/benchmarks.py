@@ -56,7 +56,9 @@ def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.
   data = task.build_inputs(exp.task.train_data, device=device, rank=rank, batch_size=cfg['B'])
   batch = next(data)       # inputs resident in HBM before the timed region
   state = {'step': 0}
-XX
+  if graph is None:
+    env = os.environ.get('MMT_STEP_GRAPH')
+    graph = (not _exchanging(world)) if env is None else env != '0'
   graph = bool(graph) and dtype == torch.bfloat16 and hasattr(optimizer, 'slabs')
 
   if graph:
