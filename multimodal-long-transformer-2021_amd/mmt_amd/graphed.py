@@ -88,8 +88,15 @@ class GraphedTrainStep:
     return self.out
 
   def close(self):
-    """Back to host-side step scalars (eager steps, other models in the process)."""
+    """Back to host-side step scalars (eager steps, other models in the process).  Also runs when the object is
+    collected: the library must not keep pointers into scalars that are gone."""
     if self.scalars is not None:
       self.scalars.disable()
       self.scalars = None
     self.graph = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass

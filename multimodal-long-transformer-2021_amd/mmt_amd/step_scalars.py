@@ -52,8 +52,16 @@ class DeviceStepScalars:
 
   def disable(self) -> None:
     global _device
-    _lib.check(_lib.lib().mmt_set_step_scalars(None, None))
-    _device = None
+    if _device is self:
+      _lib.check(_lib.lib().mmt_set_step_scalars(None, None))
+      _device = None
+
+  def __del__(self):
+    # the library holds raw pointers into these tensors: never let them outlive the registration
+    try:
+      self.disable()
+    except Exception:
+      pass
 
   def write(self, step: int, lr: float, t: int, beta1: float, beta2: float) -> None:
     e = epoch_of(step)

@@ -154,8 +154,9 @@ def _full_config(cfg_over, dtype):
   import mmt_amd
   cfg = dict(bench.config3(), **cfg_over)
   step, info = mmt_amd.make_train_step_bench(cfg, torch.device('cuda', 0), 0, 1, dtype=dtype)
-  losses = [float(step()['loss']) for _ in range(6)]
+  losses = [float(step()['loss']) for _ in range(6)]       # (three eager steps, the recording, two replays)
   torch.cuda.synchronize()
+  step.close()
   assert all(np.isfinite(losses)), losses
   assert losses[-1] < losses[0], losses          # same batch every step: the loss must fall
   return losses

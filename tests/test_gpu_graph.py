@@ -24,6 +24,7 @@ def test_dropout_epoch_on_the_device_equals_the_host_sum():
   b = torch.randn(768, device='cuda')
   gam, bet = torch.randn(768, device='cuda'), torch.randn(768, device='cuda')
   seed, epoch = 0x1234_5678_9ABC, step_scalars.epoch_of(77)
+  assert not step_scalars.device_active() and step_scalars.host_epoch() == 0      # nothing left behind by other tests
 
   def run(s):
     out, lse = mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat, dropout_p=0.2, dropout_seed=s)
