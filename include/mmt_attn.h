@@ -111,6 +111,11 @@ const char* mmt_last_error(void);
  * (src/tasks/pretraining.py:224-298) is a tf.function whose step-dependent values are tf.Variables for the same reason. */
 int mmt_set_step_scalars(const uint64_t* dropout_epoch, const float* adamw_hyper);
 
+/* Writes one step's values into those two device locations with ONE small launch on `stream` (the values travel as
+ * kernel arguments, so the host may be any number of steps ahead of the device). */
+int mmt_write_step_scalars(uint64_t* dropout_epoch, float* adamw_hyper, uint64_t epoch, float lr,
+                           float bias_correction1, float bias_correction2, void* stream);
+
 /* Bytes of scratch mmt_attn_fwd / mmt_attn_bwd need for this descriptor (the larger of
  * the two).  Host-only computation. */
 size_t mmt_workspace_bytes(const mmt_attn_desc* desc);

@@ -49,4 +49,5 @@ hipError_t launch_attn_bwd(const BwdParams& p, int, bool, hipStream_t) {
   return hipSuccess;
 }
 hipError_t launch_side_inputs(const SideParams&, hipStream_t) { ++g_launches; g_last_kind = 6; return hipSuccess; }
+hipError_t launch_write_step_scalars(unsigned long long*, float*, unsigned long long, float, float, float, hipStream_t) { ++g_launches; g_last_kind = 7; return hipSuccess; }
 }  // namespace mmt

@@ -107,5 +107,8 @@ struct SideParams {
   int32_t *att_mask, *rel_ids, *segment_ids;
 };
 hipError_t launch_side_inputs(const SideParams& p, hipStream_t st);
+// mmt_write_step_scalars: one thread writes the step's epoch and {lr, bias corrections} (side_inputs.hip)
+hipError_t launch_write_step_scalars(unsigned long long* epoch_dst, float* hyper_dst, unsigned long long epoch, float lr,
+                                     float bc1, float bc2, hipStream_t st);
 
 }  // namespace mmt

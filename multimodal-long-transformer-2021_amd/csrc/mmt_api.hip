@@ -169,6 +169,15 @@ extern "C" {
 
 int mmt_abi_version(void) { return MMT_ABI_VERSION; }
 
+int mmt_write_step_scalars(uint64_t* dropout_epoch, float* adamw_hyper, uint64_t epoch, float lr,
+                           float bias_correction1, float bias_correction2, void* stream) {
+  if (!dropout_epoch && !adamw_hyper) return fail(MMT_E_INVALID, "mmt_write_step_scalars: both destinations are NULL");
+  const hipError_t e = mmt::launch_write_step_scalars(reinterpret_cast<unsigned long long*>(dropout_epoch), adamw_hyper,
+                                                      (unsigned long long)epoch, lr, bias_correction1, bias_correction2,
+                                                      reinterpret_cast<hipStream_t>(stream));
+  return e == hipSuccess ? MMT_OK : fail(MMT_E_LAUNCH, "mmt_write_step_scalars: %s", hipGetErrorString(e));
+}
+
 int mmt_set_step_scalars(const uint64_t* dropout_epoch, const float* adamw_hyper) {
   mmt::g_dropout_epoch = reinterpret_cast<const unsigned long long*>(dropout_epoch);
   mmt::g_adamw_hyper = adamw_hyper;

@@ -65,4 +65,16 @@ hipError_t launch_side_inputs(const SideParams& p, hipStream_t st) {
   return hipGetLastError();
 }
 
+__global__ void write_step_scalars_kernel(unsigned long long* e, float* h, unsigned long long epoch, float lr, float bc1, float bc2) {
+  if (threadIdx.x == 0) {
+    if (e) *e = epoch;
+    if (h) { h[0] = lr; h[1] = bc1; h[2] = bc2; }
+  }
+}
+hipError_t launch_write_step_scalars(unsigned long long* epoch_dst, float* hyper_dst, unsigned long long epoch, float lr,
+                                     float bc1, float bc2, hipStream_t st) {
+  hipLaunchKernelGGL(write_step_scalars_kernel, dim3(1), dim3(64), 0, st, epoch_dst, hyper_dst, epoch, lr, bc1, bc2);
+  return hipGetLastError();
+}
+
 }  // namespace mmt

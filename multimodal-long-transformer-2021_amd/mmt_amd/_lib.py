@@ -19,7 +19,7 @@ MMT_IDS_NONE, MMT_IDS_1D, MMT_IDS_2D = 0, 1, 2
 MMT_FLAG_SCALE_BEFORE_ADD = 1
 MMT_FLAG_ACCUM_REL_GRADS = 2
 
-EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_set_step_scalars', 'mmt_workspace_bytes', 'mmt_attn_fwd',
+EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_set_step_scalars', 'mmt_write_step_scalars', 'mmt_workspace_bytes', 'mmt_attn_fwd',
            'mmt_attn_bwd', 'mmt_side_inputs',
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
@@ -191,6 +191,8 @@ def lib() -> ctypes.CDLL:
   L.mmt_accumulate_grad.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
   L.mmt_set_step_scalars.restype = ctypes.c_int
   L.mmt_set_step_scalars.argtypes = [vp, vp]
+  L.mmt_write_step_scalars.restype = ctypes.c_int
+  L.mmt_write_step_scalars.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
   if L.mmt_abi_version() != MMT_ABI_VERSION:
     raise ImportError('libmmt_attn ABI version mismatch')
   _lib = L

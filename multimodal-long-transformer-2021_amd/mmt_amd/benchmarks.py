@@ -62,7 +62,8 @@ def make_train_step_bench(cfg: dict, device, rank: int, world: int, dtype=torch.
   graph = bool(graph) and dtype == torch.bfloat16 and hasattr(optimizer, 'slabs')
 
   if graph:
-    graphed_step = graphed.GraphedTrainStep(task, model, optimizer, reducer, opt_cfg, clip_norm=opt_cfg.gradient_clip_norm)
+    graphed_step = graphed.GraphedTrainStep(task, model, optimizer, reducer, opt_cfg, clip_norm=opt_cfg.gradient_clip_norm,
+                                            static_inputs=True)     # the batch is resident and the same every step
 
     def step():
       state['step'] += 1

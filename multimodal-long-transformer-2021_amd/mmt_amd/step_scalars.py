@@ -38,7 +38,7 @@ def device_active() -> bool:
 
 class DeviceStepScalars:
   """The device-resident copy: one uint64 epoch and {lr, 1 - beta1^t, 1 - beta2^t}.  `write` queues their new values on
-  the current stream (fill kernels: the values travel as kernel arguments, so the host may run any number of steps
+  the current stream (one small launch: the values travel as kernel arguments, so the host may run any number of steps
   ahead of the device)."""
 
   def __init__(self, device):
@@ -64,8 +64,7 @@ class DeviceStepScalars:
       pass
 
   def write(self, step: int, lr: float, t: int, beta1: float, beta2: float) -> None:
-    e = epoch_of(step)
-    self.epoch.fill_(e - (1 << 64) if e >= (1 << 63) else e)       # the same 64 bits as a signed value
-    self.hyper[0:1].fill_(float(lr))
-    self.hyper[1:2].fill_(1.0 - beta1 ** t)
-    self.hyper[2:3].fill_(1.0 - beta2 ** t)
+    dev = self.epoch.device
+    with torch.cuda.device(dev):
+      _lib.check(_lib.lib().mmt_write_step_scalars(self.epoch.data_ptr(), self.hyper.data_ptr(), epoch_of(step), float(lr),
+                                                  1.0 - beta1 ** t, 1.0 - beta2 ** t, torch.cuda.current_stream(dev).cuda_stream))
