@@ -66,6 +66,7 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
         and task.compute_dtype == torch.bfloat16):
       graphed_step = graphed.GraphedTrainStep(task, model, optimizer, reducer, opt_cfg, metrics=train_metrics,
                                               clip_norm=opt_cfg.gradient_clip_norm)
+    run_experiment.last_step_launch = 'graph' if graphed_step is not None else 'eager'
     for step in range(start, steps):
       if graphed_step is not None:
         out = graphed_step(next(data), step + 1)

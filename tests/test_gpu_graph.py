@@ -85,3 +85,28 @@ def test_graphed_train_step_matches_the_eager_one():
   assert res[False][0] == res[True][0]
   assert torch.equal(res[False][1], res[True][1])
   assert len(set(res[True][0])) > 5                   # (the loss does move: the replays are not one frozen step)
+
+
+def test_trainer_loop_graphed_equals_eager(tmp_path, monkeypatch):
+  """`train.run_experiment` (new batch every step, metrics updated inside the step, checkpoint at the end): the logs of
+  the graphed loop equal the eager loop's, and both checkpoints carry the same step count and parameters."""
+  from tests.test_gpu_encoder import tiny_experiment
+  from mmt_amd import checkpoint, train
+  logs, ckpts = {}, {}
+  for mode in ('0', '1'):
+    monkeypatch.setenv('MMT_STEP_GRAPH', mode)
+    exp = tiny_experiment(S=256, radius=32, n_global=8)
+    exp.override({'task': {'model': {'encoder': {'mmt': {'hidden_dropout_prob': 0.1, 'attention_probs_dropout_prob': 0.1}}},
+                           'train_data': {'global_batch_size': 8}, 'micro_batch_size': 8},
+                  'runtime': {'mixed_precision_dtype': 'bfloat16'},
+                  'trainer': {'train_steps': 9, 'checkpoint_interval': 0}})
+    d = tmp_path / mode
+    d.mkdir()
+    model, lg = train.run_experiment(exp, 'train', str(d), log_every=1)
+    assert train.run_experiment.last_step_launch == ('graph' if mode == '1' else 'eager')
+    logs[mode] = [{k: v for k, v in e.items() if k != 'elapsed_s'} for e in lg]
+    ckpts[mode] = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()]).cpu()
+    assert checkpoint.latest_checkpoint(str(d))
+  assert logs['0'] == logs['1']
+  assert torch.equal(ckpts['0'], ckpts['1'])
+  assert len({e['loss'] for e in logs['1']}) > 4
