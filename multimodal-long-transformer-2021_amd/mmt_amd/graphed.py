@@ -13,6 +13,7 @@ Same numbers as the eager step: the kernels are deterministic and the seeds are 
 The reference's counterpart is the `tf.function` around its train step (src/tasks/pretraining.py:224-298)."""
 from __future__ import annotations
 
+import warnings
 from typing import Optional
 
 import torch
@@ -73,18 +74,27 @@ class GraphedTrainStep:
     t_before = self.optimizer.t
     torch.cuda.synchronize(dev)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-      self.out = self.task.train_step(self.static_batch, self.model, self.optimizer, metrics=self.metrics,
-                                      reducer=self.reducer, clip_norm=self.clip_norm, step=step)
+    try:
+      with torch.cuda.graph(graph):
+        self.out = self.task.train_step(self.static_batch, self.model, self.optimizer, metrics=self.metrics,
+                                        reducer=self.reducer, clip_norm=self.clip_norm, step=step)
+    finally:
+      self.optimizer.t = t_before          # recording runs nothing: the step itself is the first replay
     self.graph = graph
-    self.optimizer.t = t_before            # recording runs nothing: the step itself is the first replay
 
   def __call__(self, batch, step: int):
     if self.graph is None:
       if self.eager_left > 0:
         self.eager_left -= 1
         return self._eager(batch, step)
-      self._record(batch, step)
+      try:
+        self._record(batch, step)
+      except Exception as e:               # something in this configuration cannot be captured: stay eager, say so once
+        warnings.warn(f'train step not recorded as a HIP graph ({type(e).__name__}: {e}); continuing with eager steps')
+        self.close()
+        self.eager_left = 1 << 62
+        torch.cuda.synchronize()
+        return self._eager(batch, step)
     self._copy_in(batch)
     self._write_scalars(step)
     self.graph.replay()

@@ -110,3 +110,28 @@ def test_trainer_loop_graphed_equals_eager(tmp_path, monkeypatch):
   assert logs['0'] == logs['1']
   assert torch.equal(ckpts['0'], ckpts['1'])
   assert len({e['loss'] for e in logs['1']}) > 4
+
+
+def test_a_step_that_cannot_be_recorded_stays_eager(monkeypatch):
+  """If the recording raises, the step object warns once, drops its device scalars and keeps running eager steps."""
+  from mmt_amd import step_scalars
+  step = _small_step(True)
+  for _ in range(3):
+    step()
+  gs = [c.cell_contents for c in step.__closure__ if hasattr(c.cell_contents, '_record')][0]
+  task = gs.task
+  real = task.train_step
+  calls = {'n': 0}
+
+  def flaky(*a, **k):
+    calls['n'] += 1
+    if calls['n'] == 1:
+      raise RuntimeError('not capturable')
+    return real(*a, **k)
+  monkeypatch.setattr(task, 'train_step', flaky)
+  with pytest.warns(UserWarning, match='not recorded as a HIP graph'):
+    l4 = float(step()['loss'])
+  assert gs.graph is None and not step_scalars.device_active()
+  l5 = float(step()['loss'])
+  assert np.isfinite(l4) and np.isfinite(l5) and gs.optimizer.t == 5
+  step.close()
