@@ -381,7 +381,7 @@ def main():
                   'one attention-forward call, B=4 (mmt_attn_fwd: ONE launch -- window kernel: band blocks with a shared '
                   'K/V window, peeled global keys, flipped global-row workgroups)', us_prof)
   roofline_bwd = roof(bwd_ms, bwd_byts, 2.5 * flops, traffic_bwd,
-                      'one attention-backward call, B=4 (mmt_attn_bwd: dQ pass + dK/dV pass + table-gradient reduce)', us_prof_bwd)
+                      'one attention-backward call, B=4 (mmt_attn_bwd: dQ pass, which hands its probabilities to the dK/dV pass, + dK/dV pass + table-gradient reduce)', us_prof_bwd)
 
   if rank == 0:
     cpu = cpu_fb = cpu_step = None
