@@ -22,10 +22,12 @@ _state = {'done': False, 'loaded': False}
 
 
 def ensure(path: str = TUNED_FILE) -> bool:
-  """Idempotent; returns True when the tuned selections were loaded."""
+  """Idempotent; returns True when the tuned selections were loaded.  MMT_GEMM_TUNING_FILE names another selections
+  file (A/B of a re-measurement against the shipped one)."""
   if _state['done']:
     return _state['loaded']
   _state['done'] = True
+  path = os.environ.get('MMT_GEMM_TUNING_FILE', path)
   if (os.environ.get('MMT_GEMM_TUNING', '1') == '0' or os.environ.get('PYTORCH_TUNABLEOP_ENABLED') is not None
       or not torch.cuda.is_available() or not os.path.exists(path)):
     return False
