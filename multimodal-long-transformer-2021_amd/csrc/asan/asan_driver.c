@@ -95,6 +95,12 @@ int main(void) {
   CHECK(mmt_side_inputs(&m, 1, 8, NULL, NULL, 0, NULL, (int32_t*)dummy, NULL, NULL) == MMT_E_INVALID);   /* image longer than S */
   CHECK(mmt_side_inputs(&m, 1, 64, NULL, NULL, 0, NULL, (int32_t*)dummy, NULL, NULL) == MMT_OK && g_last_kind == 6);
   CHECK(mmt_side_inputs(NULL, 1, 64, NULL, NULL, 0, NULL, NULL, NULL, NULL) == MMT_E_INVALID);
+  /* ---- per-step scalars in device memory (ABI 3) ---- */
+  CHECK(mmt_set_step_scalars(NULL, NULL) == MMT_OK);
+  CHECK(mmt_write_step_scalars(NULL, NULL, 1, 1e-4f, 0.1f, 0.001f, NULL) == MMT_E_INVALID);
+  CHECK(mmt_write_step_scalars((uint64_t*)dummy, (float*)dummy, 1, 1e-4f, 0.1f, 0.001f, NULL) == MMT_OK && g_last_kind == 7);
+  CHECK(mmt_set_step_scalars((const uint64_t*)dummy, (const float*)dummy) == MMT_OK);
+  CHECK(mmt_set_step_scalars(NULL, NULL) == MMT_OK);
   printf("asan driver ok: %d stand-in launches, no sanitizer report\n", g_launches);
   return 0;
 }

@@ -10,7 +10,8 @@ extern "C" {
 const unsigned char* g_ws_lo = nullptr;
 const unsigned char* g_ws_hi = nullptr;
 int g_launches = 0;
-int g_last_kind = 0;   // 1 fwd general, 2 fwd band, 3 fwd window, 4 rows combine, 5 bwd, 6 side inputs
+int g_last_kind = 0;   // 1 fwd general, 2 fwd band, 3 fwd window, 4 rows combine, 5 bwd, 6 side inputs, 7 step scalars
+int g_last_handover = 0;   // the last backward asked for the P hand-over
 }
 
 namespace {
@@ -37,14 +38,19 @@ hipError_t launch_attn_fwd_win_bf16(const FwdParams&, hipStream_t) { ++g_launche
 int fwd_win_lds_bytes(int ng, int tstride) { return 65536 + (ng ? (2 * ((ng + 7) / 8) + 1) * 1024 : 0) + 512 * tstride; }
 hipError_t launch_rows_combine(const FwdParams&, bool, hipStream_t) { ++g_launches; g_last_kind = 4; return hipSuccess; }
 hipError_t launch_attn_bwd(const BwdParams& p, int, bool, hipStream_t) {
-  ++g_launches; g_last_kind = 5;
+  ++g_launches; g_last_kind = 5; g_last_handover = p.ho != nullptr;
   const size_t bn = (size_t)p.B * p.N, slots = bn * p.n_gblk * p.n_chunks;
   inside(p.delta, bn * p.S * 4, "delta");
   inside(p.relfar, bn * p.S * 2 * 4, "relfar");
   inside(p.drel, bn * (size_t)p.pat.ng * p.Rp * 4, "drel");
   inside(p.part_dq, slots * 32 * 64 * 4, "part_dq");
   inside(p.part_dtab, slots * 32 * p.Rp * 4, "part_dtab");
-  inside(p.part_dkv, slots * 2 * 32 * 64 * 4, "part_dkv");
+  inside(p.part_dkv, bn * p.n_gblk * (size_t)p.dkv_slots * 2 * 32 * 64 * 4, "part_dkv");
+  if (p.ho) {          // P hand-over: band tiles, global-key strips, global-row tiles (attn_kernels.h)
+    const size_t n_tiles = (size_t)(p.S + 31) / 32;
+    inside(p.ho, bn * n_tiles * ((size_t)p.ho_slots * 2048 + 512 + 512), "ho");
+    if (p.dkv_slots != p.n_chunks + (p.n_gblk > 0 ? 1 : 0)) { std::fprintf(stderr, "asan driver: hand-over without its partial slot\n"); std::abort(); }
+  }
   inside(p.part_red, bn * ((p.S + 127) / 128) * 4 * ((size_t)p.Rp * 64 + p.Rp) * 4, "part_red");
   return hipSuccess;
 }
