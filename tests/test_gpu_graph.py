@@ -87,9 +87,11 @@ def test_graphed_train_step_matches_the_eager_one():
   assert len(set(res[True][0])) > 5                   # (the loss does move: the replays are not one frozen step)
 
 
-def test_trainer_loop_graphed_equals_eager(tmp_path, monkeypatch):
+@pytest.mark.parametrize('micro', [8, 4], ids=['one-micro-step', 'two-micro-steps'])
+def test_trainer_loop_graphed_equals_eager(tmp_path, monkeypatch, micro):
   """`train.run_experiment` (new batch every step, metrics updated inside the step, checkpoint at the end): the logs of
-  the graphed loop equal the eager loop's, and both checkpoints carry the same step count and parameters."""
+  the graphed loop equal the eager loop's, and both checkpoints carry the same step count and parameters -- also with
+  the reference's micro-batch accumulation inside the recorded step (two micro-steps, the reducer armed for the last)."""
   from tests.test_gpu_encoder import tiny_experiment
   from mmt_amd import checkpoint, train
   logs, ckpts = {}, {}
@@ -97,7 +99,7 @@ def test_trainer_loop_graphed_equals_eager(tmp_path, monkeypatch):
     monkeypatch.setenv('MMT_STEP_GRAPH', mode)
     exp = tiny_experiment(S=256, radius=32, n_global=8)
     exp.override({'task': {'model': {'encoder': {'mmt': {'hidden_dropout_prob': 0.1, 'attention_probs_dropout_prob': 0.1}}},
-                           'train_data': {'global_batch_size': 8}, 'micro_batch_size': 8},
+                           'train_data': {'global_batch_size': 8}, 'micro_batch_size': micro},
                   'runtime': {'mixed_precision_dtype': 'bfloat16'},
                   'trainer': {'train_steps': 9, 'checkpoint_interval': 0}})
     d = tmp_path / mode
