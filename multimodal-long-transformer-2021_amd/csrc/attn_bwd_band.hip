@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
   else w.set_band(p.pat, live ? q0 : 0, p.S);
   // The (<= 8) global keys outside this wave's band tiles: not a sixth tile of the walk but a PEELED step before it
   // (registers 0..3 only: a quarter of a tile's VALU work, half of its dQ MFMAs, one K and one V load instruction).
-  const bool peel = REL != 2 && (p.peel_gkeys & 1) && !split_item && live &&
+  const bool peel = (p.peel_gkeys & 1) && !split_item && live &&
                     !(p.pat.g0 >= w.b0 * 32 && p.pat.g0 + p.pat.ng - 1 <= (w.b0 + w.lenB) * 32 - 1);
-  if (REL != 2 && (p.peel_gkeys & 1) && !split_item) { w.lenA = 0; w.lenC = 0; }
+  if ((p.peel_gkeys & 1) && !split_item) { w.lenA = 0; w.lenC = 0; }
   const int n_it = live ? w.count() : 0;
 
   Frag<T> qf, dof;
@@ -326,15 +326,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_band_bf16_kernel(const Bwd
     for (int i = 0; i < 4; ++i) {
       const int kk = kg0 + i + 4 * h;
       const bool present = (i + 4 * h < n_here) && !(kk >= lo_k && kk <= hi_k) && q_ok && kk < p.S;
-      const bool neg = kk < q;                             // beyond the radius on that side: clipped id
-      float sc = fmaf(c[i], p.sscale, HAS_REL ? (neg ? relfn : relfp) : 0.f);
+      const bool neg = kk < q;                             // beyond the radius on that side: clipped id (1-D)
+      int col4_i = 0;                                      // 2-D ids: byte offset of the pair's table column
+      float rel_i = HAS_REL ? (neg ? relfn : relfp) : 0.f;
+      if (REL == 2) {
+        col4_i = 4 * col2d<Rp>(p.pat, p.R, q, min(kk, p.S - 1));
+        rel_i = *(lds_cfp)(size_t)(unsigned)(trow_addr + col4_i);
+      }
+      float sc = fmaf(c[i], p.sscale, rel_i);
       sc = ((kk < valid_len) == qv) ? sc : sc + p.mask_add;
       const float pr = present ? __builtin_amdgcn_exp2f(sc - lse2) : 0.f;
       float f = 1.f;
       if (p.drop_thresh) f = drop_bits16(drop_base, (uint32_t)kk) >= p.drop_thresh ? p.inv_keep : 0.f;
       ds[i] = pr * (dp[i] * f - delta);
       pd4[i] = f != 0.f ? pr : -pr;
-      if (HAS_REL) { far_neg_acc += neg ? ds[i] : 0.f; far_pos_acc += neg ? 0.f : ds[i]; }
+      if (REL == 2) lds_add_f32(dtrow_addr + col4_i, ds[i] * p.rel_gscale);       // (0 when the pair is not present)
+      else if (HAS_REL) { far_neg_acc += neg ? ds[i] : 0.f; far_pos_acc += neg ? 0.f : ds[i]; }
     }
     if (p.ho) {              // the strip of this q block: rows x the 8 global keys (zeros where a band tile holds the pair)
       unsigned char* sp = ho_strip(p, n_tiles, bn, q0 >> 5) + lane * 8;
@@ -1508,7 +1515,7 @@ static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
   if (p.n_gblk > 0 && !ride && (e = launch_bwd_dq_combine(p, true, st)) != hipSuccess) return e;
   p.comb_in_next = ride ? 1 : 0;
   dim3 grid_kv(grid.x + (ride ? (p.pat.ng * p.B * p.N + 3) / 4 : 0));
-  if (p.ho && REL != 2) {
+  if (p.ho) {
     int win = p.ho_slots <= 5 ? 1 : 0;               // q window of a 128-key workgroup: 4 + ho_slots - 1 <= 8 tiles
     if (const char* v = std::getenv("MMT_HO_WIN")) win = win && std::atoi(v);
     if (win) {

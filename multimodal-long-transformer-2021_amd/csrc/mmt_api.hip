@@ -52,7 +52,7 @@ struct Plan {
 // P / dS hand-over between the two backward passes (lean bf16 kernels, 1-D or no relative ids): shapes it is built for.
 // The global tokens, if any, must be the peeled kind (<= 8, contiguous); the band at most 8 tiles wide.
 int handover_slots(const mmt_attn_desc* d, bool dense) {
-  if (dense || d->dtype != MMT_BF16 || d->mask.id_mode == MMT_IDS_2D) return 0;
+  if (dense || d->dtype != MMT_BF16) return 0;
   if (d->mask.global_index || d->mask.n_global > 8) return 0;
   const int W = d->mask.local_radius > d->S ? d->S : d->mask.local_radius;
   const int slots = 2 * ((W + 31) / 32) + 1;
@@ -322,12 +322,13 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   if (const char* v = std::getenv("MMT_DQ_PLANE_MAJOR")) p.dq_plane_major = std::atoi(v);
   // peeled global keys need clipped relative ids only: every peeled key lies beyond the radius, hence beyond max_dist
   p.peel_gkeys = (!dense && pl.split_rows && p.pat.ng <= 8 && (p.pat.id_mode == 0 || (p.perm_1d && p.pat.radius >= p.pat.m))) ? 3 : 0;
+  if (!dense && pl.split_rows && p.pat.ng <= 8 && p.lean2d) p.peel_gkeys = 1;      // 2-D ids: the dQ pass's peeled step looks its columns up (the recomputing dK/dV pass keeps its tile visit)
   if (const char* v = std::getenv("MMT_BWD_PEEL")) p.peel_gkeys &= std::atoi(v);      // bit 0: dQ pass, bit 1: dK/dV pass
   p.dkv_slots = p.n_chunks;
   {   // P / dS hand-over: the dK/dV pass reads what the dQ pass computed (needs the peeled kind of global tokens, if any)
     int on = 1;
     if (const char* v = std::getenv("MMT_BWD_HANDOVER")) on = std::atoi(v);
-    const bool lean = desc->dtype == MMT_BF16 && !dense && (p.pat.id_mode == 0 || p.perm_1d);
+    const bool lean = desc->dtype == MMT_BF16 && !dense && (p.pat.id_mode == 0 || p.perm_1d || p.lean2d);
     if (on && lean && pl.ho_slots > 0 && (p.pat.ng == 0 || !pl.split_rows || (p.peel_gkeys & 1))) {
       p.ho = reinterpret_cast<unsigned char*>(ws + pl.off_ho);
       p.ho_slots = pl.ho_slots;

@@ -178,7 +178,10 @@ DKV_FORMS = {'recompute': {'MMT_BWD_HANDOVER': '0'}, 'handover-wave': {'MMT_HO_W
     dict(B=1, S=20, N=2, R=9, radius=4, g0=0, ng=1),
     dict(B=1, S=96, N=1, R=32, radius=200, g0=40, ng=8, m=12),                        # radius beyond the sequence: no split items
     dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),
-], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'm')))
+    # 2-D ids (look-up-table tiles, table width 32): the dQ pass's peeled global keys look their columns up
+    dict(B=2, S=1200, N=2, R=49, radius=64, g0=1100, ng=8, id_mode=2, m=12, P=33, r=1, valid=[1200, 1111]),
+    dict(B=1, S=200, N=2, R=49, radius=20, g0=150, ng=5, id_mode=2, m=12, P=10, r=2),
+], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'm', 'id_mode')))
 def test_dkv_pass_forms(cfg, form, monkeypatch):
   """The dK/dV pass that recomputes S / dP / P (attn_bwd_dkv_band_bf16_kernel) and the two forms that read the dQ
   pass's probabilities (attn_bwd_dkv_ho_kernel: per-wave tiles, workgroup window), each against the oracle."""
