@@ -137,3 +137,29 @@ def test_a_step_that_cannot_be_recorded_stays_eager(monkeypatch):
   l5 = float(step()['loss'])
   assert np.isfinite(l4) and np.isfinite(l5) and gs.optimizer.t == 5
   step.close()
+
+
+def test_classification_trainer_loop_graphed_equals_eager(tmp_path, monkeypatch):
+  """The same comparison for `mmt/classification` (its own train_step surface: logits of one head, AUC / accuracy
+  metrics updated inside the recorded step)."""
+  from tests.test_gpu_encoder import tiny_experiment
+  from mmt_amd import configs, train
+  pre = tiny_experiment(S=256, radius=32, n_global=8)
+  logs, params = {}, {}
+  for mode in ('0', '1'):
+    monkeypatch.setenv('MMT_STEP_GRAPH', mode)
+    exp = configs.get_exp_config('mmt/classification')
+    enc = pre.task.model.encoder.as_dict()
+    enc['mmt'].update(hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    exp.override({'task': {'model': {'encoder': enc, 'cls_heads': [{'inner_dim': 64, 'num_classes': 2, 'name': 'itm'}]},
+                           'train_data': dict(pre.task.train_data.as_dict(), global_batch_size=8), 'micro_batch_size': 8},
+                  'runtime': {'mixed_precision_dtype': 'bfloat16'},
+                  'trainer': {'train_steps': 8, 'checkpoint_interval': 0}}, strict=False)
+    d = tmp_path / mode
+    d.mkdir()
+    model, lg = train.run_experiment(exp, 'train', str(d), log_every=1)
+    assert train.run_experiment.last_step_launch == ('graph' if mode == '1' else 'eager')
+    logs[mode] = [{k: v for k, v in e.items() if k != 'elapsed_s'} for e in lg]
+    params[mode] = torch.cat([p.detach().float().reshape(-1) for p in model.parameters()]).cpu()
+  assert logs['0'] == logs['1']
+  assert torch.equal(params['0'], params['1'])
