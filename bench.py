@@ -33,8 +33,40 @@ MFMA_BF16_PEAK_TF = 2500.0   # dense bf16 MFMA
 XGMI_LINK_GBS = 153.0        # per xGMI link, 7 links per GPU
 
 
+F32_MFMA_PEAK_TF = 157.3     # exact-f32 MFMA (32x32x2) = the f32 vector rate
+
+
+def traffic_file(cfg):
+  """profiles/ file that holds the PMC traffic + rocprofv3 kernel durations of this configuration's attention calls."""
+  if cfg['config'] == 3 and cfg['ng'] == 8:
+    return 'attn_traffic.json'
+  return f"r04_cfg{cfg['config']}_g{cfg['ng']}_attn_traffic.json"
+
+
 def config3():
-  return dict(S=4096, N=12, D=64, R=32, B=4, radius=64, g0=3971, ng=8, m=12, H=768, L=12, I=3072)
+  return get_config(3)
+
+
+def get_config(n=3, ng=None):
+  """The single-GPU BASELINE configurations.  S = 2 + P^2 patches + text; the global tokens
+  are the first `ng` text positions; per-GPU batch as the survey fixes it."""
+  base = dict(N=12, D=64, R=32, radius=64, m=12, H=768, L=12, I=3072)
+  if n == 2:      # BERT-base dims, S=1024 (image 448), fp32 (exact-f32 MFMA), B=8
+    base.update(S=1024, P=28, B=8, dtype='f32', name='BASELINE config 2: BERT-base dims, S=1024 (2+28^2 patches+238 text), '
+                                                     'radius 64 + {ng} global tokens, fp32, per-GPU batch 8')
+  elif n == 3:    # the headline: S=4096 (image 1008), bf16, B=4
+    base.update(S=4096, P=63, B=4, dtype='bf16', name='BASELINE config 3: BERT-base dims, S=4096 (2+63^2 patches+125 text), '
+                                                      'radius 64 + {ng} global tokens, bf16, per-GPU batch 4')
+  elif n == 5:    # Fashion-Gen-shaped S=8192 (image 1408), bf16, B=2, global tokens swept 8 / 32 / 128
+    base.update(S=8192, P=88, B=2, dtype='bf16', name='BASELINE config 5 (single-GPU shape): BERT-base dims, S=8192 (2+88^2 patches+446 text), '
+                                                      'radius 64 + {ng} global tokens, bf16, per-GPU batch 2')
+  else:
+    raise ValueError(f'no single-GPU BASELINE configuration {n}')
+  base['ng'] = 8 if ng is None else int(ng)
+  base['g0'] = 2 + base['P'] ** 2          # the [ATT] marker's position and the tokens after it
+  base['config'] = n
+  base['name'] = base['name'].format(ng=base['ng'])
+  return base
 
 
 def pattern_pairs(S, radius, g0, ng):
@@ -199,6 +231,10 @@ def main():
   ap.add_argument('--allreduce-mb', type=float, default=None,
                   help='allreduce mode: gradient bytes per rank in MB (default: the model\'s 444 MB)')
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--config', type=int, default=3, choices=[2, 3, 5],
+                  help='single-GPU BASELINE configuration (SURVEY.md 8d): 3 = the headline (default); 2 = S=1024 fp32; '
+                       '5 = S=8192 bf16 (use --globals 8|32|128)')
+  ap.add_argument('--globals', type=int, default=None, dest='n_globals', help='number of global tokens (default 8)')
   ap.add_argument('--ids2d', action='store_true',
                   help="the same workload with the 2-D relative ids of the reference's *_2d*.yaml (one core layer, "
                        'relative_vocab_size 49) instead of the 1-D ids of BASELINE config 3 -- a side measurement, not the headline')
@@ -257,10 +293,13 @@ def main():
     ranks_seen = int(t.item())
     assert ranks_seen == world, (ranks_seen, world)
 
-  cfg = config3()
+  cfg = get_config(args.config, args.n_globals)
   if args.ids2d:
-    cfg.update(R=49, core=1, P=63)
+    cfg.update(R=49, core=1)
   B, S, N, D, R = cfg['B'], cfg['S'], cfg['N'], cfg['D'], cfg['R']
+  f32 = cfg['dtype'] == 'f32'
+  tdtype = torch.float32 if f32 else torch.bfloat16
+  elt = 4 if f32 else 2
   mode = args.mode
   if mode == 'auto':
     mode = 'train_step'
@@ -275,16 +314,16 @@ def main():
     pat = mmt_amd.AttentionPattern(local_radius=cfg['radius'], global_start=cfg['g0'],
                                    n_global=cfg['ng'], id_mode=2 if args.ids2d else 1, max_dist=cfg['m'],
                                    patches_per_row=cfg.get('P', 0) if args.ids2d else 0, core_layers=cfg.get('core', 0))
-    q, k, v = (torch.randn(B, S, N, D, device=dev, generator=g).to(torch.bfloat16) for _ in range(3))
-    emb = (torch.randn(R, N, D, device=dev, generator=g) * 0.02).to(torch.bfloat16)
-    bias = (torch.randn(R, N, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    q, k, v = (torch.randn(B, S, N, D, device=dev, generator=g).to(tdtype) for _ in range(3))
+    emb = (torch.randn(R, N, D, device=dev, generator=g) * 0.02).to(tdtype)
+    bias = (torch.randn(R, N, device=dev, generator=g) * 0.02).to(tdtype)
     drop = dict(dropout_p=0.1, dropout_seed=12345)       # the train step's attention_probs_dropout_prob
 
     def attn_fwd():
       return mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat, **drop)
 
     if mode == 'train_step':
-      step_fn, step_info = mmt_amd.make_train_step_bench(cfg, dev, rank, world)
+      step_fn, step_info = mmt_amd.make_train_step_bench(cfg, dev, rank, world, dtype=tdtype)
     else:
       step_fn = attn_fwd
 
@@ -341,7 +380,7 @@ def main():
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 
-  flops, byts, bwd_byts = attn_algorithmic(cfg, 2)
+  flops, byts, bwd_byts = attn_algorithmic(cfg, elt)
   attn_ms = timed(attn_fwd)
   out, lse = attn_fwd()
   dout = torch.randn_like(out)
@@ -356,48 +395,59 @@ def main():
   traffic = traffic_bwd = traffic_commit = None   # HBM bytes per launch from the committed PMC passes
   us_prof = us_prof_bwd = None                    # rocprofv3 kernel durations of the same workload (profiles/, same commit)
   try:
-    with open(os.path.join(ROOT, 'profiles', 'attn_traffic.json')) as f:
+    with open(os.path.join(ROOT, 'profiles', traffic_file(cfg))) as f:
       tj = json.load(f)
     traffic, traffic_bwd, traffic_commit = tj['fwd_hbm_bytes_per_launch'], tj['bwd_hbm_bytes_per_launch'], tj.get('commit')
     us_prof, us_prof_bwd = tj.get('fwd_kernel_us_rocprof'), tj.get('bwd_kernel_us_rocprof')
   except (OSError, KeyError, ValueError):
     pass
 
+  mfma_peak = F32_MFMA_PEAK_TF if f32 else MFMA_BF16_PEAK_TF
+
   def roof(ms, nbytes, nflops, traffic, kernel, us_rocprof=None):
+    """Both roofline terms ("report both fractions for every run and name the binding one"): the HBM
+    fraction of the algorithmic bytes and the MFMA fraction of the algorithmic flops -- against the exact-f32 MFMA
+    rate for fp32 I/O (config 2), the dense bf16 rate otherwise; `bound` is the larger of the two."""
     gbs = nbytes * B / (ms * 1e-3) / 1e9
     tfs = nflops * B / (ms * 1e-3) / 1e12
-    return {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(gbs / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_measured_at': traffic_commit,
+    hbm_frac, mfma_frac = gbs / HBM_PEAK_GBS, tfs / mfma_peak
+    by_hbm = hbm_frac >= mfma_frac
+    us_sum = sum(us_rocprof.values()) * 1e-6 if us_rocprof else None
+    return {'bound': 'hbm' if by_hbm else ('mfma_f32' if f32 else 'mfma'),
+            'achieved': round(gbs, 1) if by_hbm else round(tfs, 2), 'peak': HBM_PEAK_GBS if by_hbm else mfma_peak,
+            'unit': 'GB/s' if by_hbm else 'TFLOP/s', 'frac': round(max(hbm_frac, mfma_frac), 4),
+            'traffic': traffic, 'traffic_measured_at': traffic_commit,
             'kernel': kernel, 'launch_us': round(ms * 1e3, 2), 'algorithmic_bytes_per_launch': nbytes * B,
-            'mfma_tflops': round(tfs, 2), 'mfma_frac': round(tfs / MFMA_BF16_PEAK_TF, 5),
+            'algorithmic_flops_per_launch': int(nflops * B),
+            'hbm_gbs': round(gbs, 1), 'hbm_frac': round(hbm_frac, 4),
+            'mfma_tflops': round(tfs, 2), 'mfma_peak_tflops': mfma_peak, 'mfma_frac': round(mfma_frac, 5),
             'dropout_p': drop['dropout_p'],
-            # per-kernel average durations under rocprofv3 --kernel-trace --stats (profiles/r03_attn_kernel_stats.csv):
-            # frac can be recomputed from them as algorithmic_bytes_per_launch / sum(us) / peak
+            # per-kernel average durations under rocprofv3 --kernel-trace --stats (profiles/*_attn_kernel_stats.csv):
+            # frac can be recomputed from them as algorithmic bytes (or flops) per launch / sum(us) / peak
             'kernel_us_rocprof': us_rocprof,
-            'frac_rocprof': (round(nbytes * B / (sum(us_rocprof.values()) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            'frac_rocprof': (round((nbytes * B / us_sum / 1e9 / HBM_PEAK_GBS) if by_hbm else (nflops * B / us_sum / 1e12 / mfma_peak), 4)
                              if us_rocprof else None)}
 
   roofline = roof(attn_ms, byts, flops, traffic,
-                  'one attention-forward call, B=4 (mmt_attn_fwd: ONE launch -- window kernel: band blocks with a shared '
-                  'K/V window, peeled global keys, flipped global-row workgroups)', us_prof)
+                  f'one attention-forward call, B={B} (mmt_attn_fwd)', us_prof)
   roofline_bwd = roof(bwd_ms, bwd_byts, 2.5 * flops, traffic_bwd,
-                      'one attention-backward call, B=4 (mmt_attn_bwd: dQ pass, which hands its probabilities to the dK/dV pass, + dK/dV pass + table-gradient reduce)', us_prof_bwd)
+                      f'one attention-backward call, B={B} (mmt_attn_bwd: dQ pass, dK/dV pass, table-gradient reduce)', us_prof_bwd)
 
   if rank == 0:
     cpu = cpu_fb = cpu_step = None
     if world == 1 and not args.no_cpu_baseline:
-      cpu = cpu_baseline_attention(cfg)
-      cpu_fb = cpu_baseline_attention(cfg, backward=True)
+      if S <= 4096:      # the dense restatement materialises [N,S,S] fp32 tensors: 3.2 GB each at S=8192 -- not run there
+        cpu = cpu_baseline_attention(cfg)
+        cpu_fb = cpu_baseline_attention(cfg, backward=True)
       cpu_step = cpu_baseline_train_step()
     line = {
-        'metric': 'train-step samples/sec + attention TFLOPS, 4096-tok seq',
+        'metric': f'train-step samples/sec + attention TFLOPS, {S}-tok seq',
         'value': round(value, 3),
         'unit': 'samples/s' if mode == 'train_step' else 'attention-layer-fwd samples/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE config 3: BERT-base dims, S=4096 (2+63^2 patches+125 text), '
-                               'radius 64 + 8 global tokens, bf16, per-GPU batch 4'
+        'vs_baseline': None, 'dtype': 'f32' if f32 else 'bf16', 'data': 'synthetic',
+        'config': {'workload': cfg['name']
                                + (' -- SIDE MEASUREMENT with the 2-D relative ids of *_2d*.yaml (1 core layer, R=49)' if args.ids2d else ''),
                    'step': mode, 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': S,
                    'parallelism': f'dp{world}', 'backend': backend if (world > 1 or force_dist) else None,

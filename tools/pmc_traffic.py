@@ -1,7 +1,7 @@
 """Dev tool: per-kernel means of FETCH_SIZE / WRITE_SIZE from two rocprofv3 --pmc passes over tools/attn_pmc_workload.py
 -> profiles/attn_traffic.json (read by bench.py for roofline.traffic / roofline_bwd.traffic), stamped with the commit.
 gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE x2 for wide (16 B/lane) streaming reads, WRITE_SIZE as is; unit KB."""
-import csv, json, collections, subprocess, sys
+import csv, json, collections, os, subprocess, sys
 sys.path.insert(0, '.')
 import bench
 def means(path, counter):
@@ -10,27 +10,29 @@ def means(path, counter):
     if r['Counter_Name'] == counter and ('attn' in r['Kernel_Name'] or 'drel' in r['Kernel_Name']):
       acc[r['Kernel_Name'].split('(')[0]].append(float(r['Counter_Value']))
   return {k: sum(v[len(v) // 4:]) / len(v[len(v) // 4:]) for k, v in acc.items()}     # skip the first (cold) quarter
-f = means('gpurun_out/pmc_f/f_counter_collection.csv', 'FETCH_SIZE')
-w = means('gpurun_out/pmc_w/w_counter_collection.csv', 'WRITE_SIZE')
+# usage: [MMT_BENCH_CONFIG=n MMT_BENCH_GLOBALS=g] python tools/pmc_traffic.py [directory prefix of the three passes, default gpurun_out/]
+pre = sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/'
+f = means(pre + 'pmc_f/f_counter_collection.csv', 'FETCH_SIZE')
+w = means(pre + 'pmc_w/w_counter_collection.csv', 'WRITE_SIZE')
 is_fwd = lambda k: 'attn_fwd' in k or 'rows_combine' in k
 hbm = lambda ks: int(sum((2 * f[k] + w.get(k, 0.0)) * 1024 for k in ks))
 fwd_k, bwd_k = [k for k in f if is_fwd(k)], [k for k in f if not is_fwd(k)]
-cfg = bench.config3()
-_, fb, bb = bench.attn_algorithmic(cfg, 2)
+cfg = bench.get_config(int(os.environ.get('MMT_BENCH_CONFIG', '3')), os.environ.get('MMT_BENCH_GLOBALS'))
+_, fb, bb = bench.attn_algorithmic(cfg, 4 if cfg['dtype'] == 'f32' else 2)
 # kernel durations of the same workload under rocprofv3 --kernel-trace --stats (the third pass listed in
 # tools/attn_pmc_workload.py): average us per launch, by kernel
 ks = {}
 try:
-  for r in csv.DictReader(open('gpurun_out/attn_ks/a_kernel_stats.csv')):
+  for r in csv.DictReader(open(pre + 'attn_ks/a_kernel_stats.csv')):
     if 'attn' in r['Name'] or 'drel' in r['Name']:
       ks[r['Name'].split('(')[0]] = round(float(r['AverageNs']) / 1e3, 2)
 except OSError:
   pass
-commit = subprocess.check_output(['git', 'rev-parse', '--short=12', 'HEAD']).decode().strip()
-dirty = bool(subprocess.check_output(['git', 'status', '--porcelain', '--', 'multimodal-long-transformer-2021_amd/csrc']).decode().strip())
+commit = os.environ.get('MMT_PROFILE_COMMIT') or subprocess.check_output(['git', 'rev-parse', '--short=12', 'HEAD']).decode().strip()
+dirty = not os.environ.get('MMT_PROFILE_COMMIT') and bool(subprocess.check_output(['git', 'status', '--porcelain', '--', 'multimodal-long-transformer-2021_amd/csrc']).decode().strip())
 out = {
   'commit': commit + ('+uncommitted csrc changes' if dirty else ''),
-  'workload': 'tools/attn_pmc_workload.py: the attention forward and backward calls bench.py times (config 3, B=4, dropout 0.1)',
+  'workload': f"tools/attn_pmc_workload.py: the attention forward and backward calls bench.py times ({cfg['name']}, dropout 0.1)",
   'method': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE and, in a separate pass, --pmc WRITE_SIZE; per-kernel means over the last 3/4 '
             'of the launches; gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE x2 for wide (16 B/lane) streaming reads, '
             'WRITE_SIZE as is; unit KB',
@@ -40,5 +42,5 @@ out = {
   'bwd_kernel_us_rocprof': {k: v for k, v in ks.items() if not is_fwd(k)} or None,
   'per_kernel_raw_KB': {k: {'FETCH_SIZE': round(f[k], 1), 'WRITE_SIZE': round(w.get(k, 0.0), 1)} for k in f},
 }
-json.dump(out, open('profiles/attn_traffic.json', 'w'), indent=1)
+json.dump(out, open(os.path.join('profiles', bench.traffic_file(cfg)), 'w'), indent=1)
 print(json.dumps(out, indent=1))
