@@ -16,7 +16,10 @@
  *  - return 0 on success, a negative MMT_E_* code on failure; the message of the last
  *    failure on the calling thread is available from mmt_last_error(); nothing throws
  *    or aborts across this boundary;
- *  - re-entrant across threads and streams (no global mutable state).
+ *  - re-entrant across threads and streams: no global mutable state.  Everything a call depends on travels in its
+ *    descriptor and arguments (ABI 4: the device-resident step scalars and the kernel-selection switches too; the
+ *    library reads no environment variable).  The one exception is speed-only: the two atomic compute-unit budgets
+ *    of mmt_layer.h (mmt_wgrad_set_cu_budget / mmt_ffn_set_cu_budget), which size grids and never change a result.
  */
 #ifndef MMT_ATTN_H_
 #define MMT_ATTN_H_
@@ -28,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MMT_ABI_VERSION 3
+#define MMT_ABI_VERSION 4
 
 enum {
   MMT_OK = 0,
@@ -52,6 +55,18 @@ enum {
 /* flags */
 #define MMT_FLAG_SCALE_BEFORE_ADD 1u /* s = content*scale + rel  (default: (content+rel)*scale) */
 #define MMT_FLAG_ACCUM_REL_GRADS 2u  /* backward: drel_emb / drel_bias += (fp32 master gradients) instead of = */
+
+/* Kernel-selection switches (mmt_attn_desc.tuning; ABI 4).  0 = the library's defaults.  They choose between kernels
+ * that compute the same result (parity tests flip them to reach every kernel; they replace the MMT_* environment
+ * variables the library read until ABI 3). */
+#define MMT_TUNE_FWD_WALK 0x01u          /* forward: the plane-walk kernel (attn_fwd_walk.hip) where it covers the shape  */
+#define MMT_TUNE_FWD_NO_WIN 0x02u        /* forward: not the window kernel (attn_fwd_win.hip) either: per-wave staging  */
+#define MMT_TUNE_FWD_FORCE_WIN 0x04u     /* forward: window kernel whenever the shape is covered, whatever its LDS need */
+#define MMT_TUNE_BWD_NO_HANDOVER 0x08u   /* backward: the dK/dV pass recomputes P instead of reading the dQ pass's      */
+#define MMT_TUNE_BWD_HO_PER_WAVE 0x10u   /* backward: hand-over dK/dV pass in its per-wave form (no workgroup window)   */
+#define MMT_TUNE_BWD_NO_PEEL_DQ 0x20u    /* backward: global keys as a tile visit of the dQ pass, not a peeled step     */
+#define MMT_TUNE_BWD_NO_PEEL_DKV 0x40u   /* backward: likewise for the global query rows of the recomputing dK/dV pass  */
+#define MMT_TUNE_BWD_DQ_PLANE_MAJOR 0x80u /* backward: plane-major block placement of the dQ pass                       */
 
 /* Attention pattern + id generator.  With local_radius >= S and n_global == 0 the
  * pattern is exactly the reference's segmented mask (data_utils.py:321-322):
@@ -92,6 +107,18 @@ typedef struct mmt_attn_desc {
   float dropout_p;      /* attention_probs_dropout_prob; 0 disables                   */
   uint64_t dropout_seed;
   mmt_mask_desc mask;   /* used when att_mask / rel_ids pointers are NULL             */
+  /* ---- ABI 4 ---- */
+  const uint64_t* dropout_epoch; /* DEVICE uint64 the kernels add to dropout_seed when they start, or NULL.  For callers
+                                    that record a train step once as a HIP graph and replay it: kernel arguments are
+                                    frozen in a graph, this word is not (mmt_write_step_scalars).  Forward and backward
+                                    of one call must see the same value.                                              */
+  uint32_t tuning;               /* MMT_TUNE_* switches; 0 = defaults                                                 */
+  uint32_t sync_words;           /* length of `sync` in 32-bit words                                                   */
+  uint32_t* sync;                /* DEVICE scratch of arrival counters for kernels whose workgroups combine partial
+                                    results inside ONE launch (the forward's plane walk: B*N words), or NULL (such
+                                    kernels are then not taken).  Caller-owned like every buffer; must be all zero
+                                    before its first use; every call leaves it all zero again; calls that share it
+                                    must be ordered on one stream.                                                    */
 } mmt_attn_desc;
 
 int mmt_abi_version(void);
@@ -100,19 +127,18 @@ int mmt_abi_version(void);
 const char* mmt_last_error(void);
 
 /* Per-step scalars that live in DEVICE memory, for callers that record a train step once as a HIP graph and replay it
- * (kernel arguments are frozen in a graph; these are read by the kernels when they start):
- *   dropout_epoch : one uint64.  Every kernel of this library that draws a dropout mask (attention probabilities,
- *                   mmt_layer.h residual blocks and embedding assembly) adds *dropout_epoch to its descriptor's
- *                   dropout_seed -- forward and backward alike, so a backward still regenerates its forward's mask.
- *   adamw_hyper   : three floats {lr, bias_correction1, bias_correction2} that mmt_adamw_step uses INSTEAD of the
- *                   fields of its descriptor.
- * Either may be NULL (= off, the default).  Process-wide setting, read at every launch; the memory must stay valid
- * while launches (or graph replays) that captured it can run.  Replaces nothing in the reference: its train step
- * (src/tasks/pretraining.py:224-298) is a tf.function whose step-dependent values are tf.Variables for the same reason. */
-int mmt_set_step_scalars(const uint64_t* dropout_epoch, const float* adamw_hyper);
-
-/* Writes one step's values into those two device locations with ONE small launch on `stream` (the values travel as
- * kernel arguments, so the host may be any number of steps ahead of the device). */
+ * (kernel arguments are frozen in a graph; these words are read by the kernels when they start):
+ *   dropout_epoch : one uint64, named by the `dropout_epoch` field of mmt_attn_desc / mmt_rows_desc / mmt_embed_desc:
+ *                   the kernel adds it to the descriptor's dropout_seed -- forward and backward alike, so a backward
+ *                   still regenerates its forward's mask.
+ *   adamw_hyper   : three floats {lr, bias_correction1, bias_correction2}, named by mmt_adamw_desc.hyper, that
+ *                   mmt_adamw_step uses INSTEAD of the fields of its descriptor.
+ * The library keeps no registration of them (ABI 3's process-wide mmt_set_step_scalars is gone): two models, devices or
+ * threads in one process each pass their own words.  Replaces nothing in the reference: its train step
+ * (src/tasks/pretraining.py:224-298) is a tf.function whose step-dependent values are tf.Variables for the same reason.
+ *
+ * mmt_write_step_scalars writes one step's values into two such locations with ONE small launch on `stream` (the values
+ * travel as kernel arguments, so the host may be any number of steps ahead of the device).  Either destination may be NULL. */
 int mmt_write_step_scalars(uint64_t* dropout_epoch, float* adamw_hyper, uint64_t epoch, float lr,
                            float bias_correction1, float bias_correction2, void* stream);
 

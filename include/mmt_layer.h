@@ -37,6 +37,7 @@ typedef struct mmt_rows_desc {
                            the fixed-order reduce; the caller finishes with mmt_colsum_reduce (same desc,
                            same workspace) on a stream of its choice -- the parameter gradients are off the
                            critical path of backward                                                      */
+  const uint64_t* dropout_epoch; /* ABI 4: DEVICE uint64 added to dropout_seed by the kernel, or NULL (mmt_attn.h) */
 } mmt_rows_desc;
 
 /* Bytes of scratch the *_bwd entry points need (column-sum partials). */
@@ -125,6 +126,8 @@ typedef struct mmt_adamw_desc {
   float bias_correction1, bias_correction2;   /* 1 - beta^t */
   int32_t zero_grad;
   int32_t reserved;
+  const float* hyper;    /* ABI 4: DEVICE {lr, bias_correction1, bias_correction2} read by the kernel INSTEAD of the three
+                            fields above, or NULL (mmt_attn.h: mmt_write_step_scalars)                                 */
 } mmt_adamw_desc;
 
 int mmt_adamw_step(const mmt_adamw_desc* desc, float* param, float* grad, float* exp_avg,
@@ -197,6 +200,7 @@ typedef struct mmt_embed_desc {
   float dropout_p;       /* hidden_dropout_prob; 0 disables                              */
   int32_t accumulate;    /* backward: != 0 adds dgamma / dbeta INTO the given buffers     */
   uint64_t dropout_seed;
+  const uint64_t* dropout_epoch; /* ABI 4: DEVICE uint64 added to dropout_seed by the kernel, or NULL (mmt_attn.h) */
 } mmt_embed_desc;
 
 int mmt_embed_fwd(const mmt_embed_desc* desc, const int32_t* word_ids, const int32_t* seg_ids,

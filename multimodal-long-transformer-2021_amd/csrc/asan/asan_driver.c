@@ -9,7 +9,8 @@
 
 extern const unsigned char* g_ws_lo;
 extern const unsigned char* g_ws_hi;
-extern int g_launches, g_last_kind;
+extern int g_launches, g_last_kind, g_last_handover;
+extern const void* g_last_epoch;
 
 #define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "asan driver: %s:%d: %s (last error: %s)\n", __FILE__, __LINE__, #cond, mmt_last_error()); return 1; } } while (0)
 
@@ -95,12 +96,57 @@ int main(void) {
   CHECK(mmt_side_inputs(&m, 1, 8, NULL, NULL, 0, NULL, (int32_t*)dummy, NULL, NULL) == MMT_E_INVALID);   /* image longer than S */
   CHECK(mmt_side_inputs(&m, 1, 64, NULL, NULL, 0, NULL, (int32_t*)dummy, NULL, NULL) == MMT_OK && g_last_kind == 6);
   CHECK(mmt_side_inputs(NULL, 1, 64, NULL, NULL, 0, NULL, NULL, NULL, NULL) == MMT_E_INVALID);
-  /* ---- per-step scalars in device memory (ABI 3) ---- */
-  CHECK(mmt_set_step_scalars(NULL, NULL) == MMT_OK);
+  /* ---- per-step scalars in device memory (ABI 4: named by the descriptors, no registration in the library) ---- */
   CHECK(mmt_write_step_scalars(NULL, NULL, 1, 1e-4f, 0.1f, 0.001f, NULL) == MMT_E_INVALID);
   CHECK(mmt_write_step_scalars((uint64_t*)dummy, (float*)dummy, 1, 1e-4f, 0.1f, 0.001f, NULL) == MMT_OK && g_last_kind == 7);
-  CHECK(mmt_set_step_scalars((const uint64_t*)dummy, (const float*)dummy) == MMT_OK);
-  CHECK(mmt_set_step_scalars(NULL, NULL) == MMT_OK);
+  {   /* two descriptors with different epoch words in one process: each launch gets its own */
+    uint64_t epoch_a = 1, epoch_b = 2;
+    mmt_attn_desc da = base_desc(1, 256, 2, 32, MMT_BF16), db = base_desc(1, 256, 2, 32, MMT_BF16);
+    da.dropout_p = db.dropout_p = 0.1f;
+    da.dropout_epoch = &epoch_a; db.dropout_epoch = &epoch_b;
+    unsigned char* ws = (unsigned char*)malloc(mmt_workspace_bytes(&da) + 1);
+    g_ws_lo = ws; g_ws_hi = ws + mmt_workspace_bytes(&da) + 1;
+    CHECK(mmt_attn_fwd(&da, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, ws, mmt_workspace_bytes(&da), NULL) == MMT_OK);
+    CHECK(g_last_epoch == (const void*)&epoch_a);
+    CHECK(mmt_attn_fwd(&db, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, ws, mmt_workspace_bytes(&db), NULL) == MMT_OK);
+    CHECK(g_last_epoch == (const void*)&epoch_b);
+    CHECK(mmt_attn_bwd(&da, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, dummy, (const float*)dummy, dummy, dummy, dummy,
+                       (float*)dummy, NULL, ws, mmt_workspace_bytes(&da), NULL) == MMT_OK);
+    CHECK(g_last_epoch == (const void*)&epoch_a);
+    db.dropout_p = 0.f;                       /* no dropout: the word is not even passed on */
+    CHECK(mmt_attn_fwd(&db, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, ws, mmt_workspace_bytes(&db), NULL) == MMT_OK);
+    CHECK(g_last_epoch == NULL);
+    /* kernel-selection switches travel in the descriptor too (they were environment variables until ABI 3) */
+    da.tuning = MMT_TUNE_FWD_NO_WIN;
+    CHECK(mmt_attn_fwd(&da, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, ws, mmt_workspace_bytes(&da), NULL) == MMT_OK && g_last_kind == 2);
+    da.tuning = MMT_TUNE_FWD_FORCE_WIN;
+    CHECK(mmt_attn_fwd(&da, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, ws, mmt_workspace_bytes(&da), NULL) == MMT_OK && g_last_kind == 3);
+    {   /* the plane-walk forward needs the caller's arrival counters when there are global tokens (ABI 4: desc.sync) */
+      mmt_attn_desc dw = base_desc(4, 4096, 12, 32, MMT_BF16);
+      dw.mask.n_global = 8; dw.mask.global_start = 3971;
+      const size_t need = mmt_workspace_bytes(&dw);
+      unsigned char* w2 = (unsigned char*)malloc(need);
+      g_ws_lo = w2; g_ws_hi = w2 + need;
+      CHECK(mmt_attn_fwd(&dw, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, w2, need, NULL) == MMT_OK && g_last_kind == 3);   /* default: window kernel */
+      dw.tuning = MMT_TUNE_FWD_WALK;                             /* asked for, but no counters: still the window kernel */
+      CHECK(mmt_attn_fwd(&dw, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, w2, need, NULL) == MMT_OK && g_last_kind == 3);
+      dw.sync = (uint32_t*)dummy; dw.sync_words = 47;            /* too few words for 48 planes */
+      CHECK(mmt_attn_fwd(&dw, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, w2, need, NULL) == MMT_OK && g_last_kind == 3);
+      dw.sync_words = 48;
+      CHECK(mmt_attn_fwd(&dw, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, w2, need, NULL) == MMT_OK && g_last_kind == 8);
+      dw.tuning = 0;
+      CHECK(mmt_attn_fwd(&dw, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, w2, need, NULL) == MMT_OK && g_last_kind == 3);
+      free(w2);
+      g_ws_lo = ws; g_ws_hi = ws + mmt_workspace_bytes(&da) + 1;
+    }
+    da.tuning = MMT_TUNE_BWD_NO_HANDOVER;
+    CHECK(mmt_attn_bwd(&da, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, dummy, (const float*)dummy, dummy, dummy, dummy,
+                       (float*)dummy, NULL, ws, mmt_workspace_bytes(&da), NULL) == MMT_OK && g_last_handover == 0);
+    da.tuning = 0;
+    CHECK(mmt_attn_bwd(&da, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, dummy, (const float*)dummy, dummy, dummy, dummy,
+                       (float*)dummy, NULL, ws, mmt_workspace_bytes(&da), NULL) == MMT_OK && g_last_handover == 1);
+    free(ws);
+  }
   printf("asan driver ok: %d stand-in launches, no sanitizer report\n", g_launches);
   return 0;
 }

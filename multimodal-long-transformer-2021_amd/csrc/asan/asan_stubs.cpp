@@ -10,8 +10,9 @@ extern "C" {
 const unsigned char* g_ws_lo = nullptr;
 const unsigned char* g_ws_hi = nullptr;
 int g_launches = 0;
-int g_last_kind = 0;   // 1 fwd general, 2 fwd band, 3 fwd window, 4 rows combine, 5 bwd, 6 side inputs, 7 step scalars
+int g_last_kind = 0;   // 1 fwd general, 2 fwd band, 3 fwd window, 4 rows combine, 5 bwd, 6 side inputs, 7 step scalars, 8 fwd plane walk
 int g_last_handover = 0;   // the last backward asked for the P hand-over
+const void* g_last_epoch = nullptr;   // the device epoch word the last attention launch was given
 }
 
 namespace {
@@ -27,18 +28,39 @@ void inside(const void* p, size_t bytes, const char* what) {
 
 namespace mmt {
 hipError_t launch_attn_fwd(const FwdParams& p, int, bool, hipStream_t) {
-  ++g_launches; g_last_kind = 1;
+  ++g_launches; g_last_kind = 1; g_last_epoch = p.epoch;
   const size_t slots = (size_t)p.B * p.N * p.n_rowblk * p.n_chunks;
   inside(p.part_o, slots * 32 * 64 * 4, "part_o");
   inside(p.part_ml, slots * 64 * 4, "part_ml");
   return hipSuccess;
 }
 hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st) { hipError_t e = launch_attn_fwd(p, 0, true, st); g_last_kind = 2; return e; }
-hipError_t launch_attn_fwd_win_bf16(const FwdParams&, hipStream_t) { ++g_launches; g_last_kind = 3; return hipSuccess; }
+hipError_t launch_attn_fwd_win_bf16(const FwdParams& p, hipStream_t) { ++g_launches; g_last_kind = 3; g_last_epoch = p.epoch; return hipSuccess; }
+hipError_t launch_attn_fwd_walk_bf16(const FwdParams& p, int grid, hipStream_t) {
+  ++g_launches; g_last_kind = 8; g_last_epoch = p.epoch;
+  if (p.pat.ng > 0) inside(p.walk_part, (size_t)p.B * p.N * p.walk_maxseg * 8 * 66 * 4, "walk_part");
+  const int per_group = grid / p.walk_groups, ppg = p.B * p.N / p.walk_groups;
+  if (grid <= 0 || per_group != ppg * p.walk_nseg + p.walk_nhi || p.walk_nseg < 1 || p.walk_maxseg > ((p.S + 31) / 32 + 1) / 2) {
+    std::fprintf(stderr, "asan driver: inconsistent plane-walk plan\n"); std::abort();
+  }
+  return hipSuccess;
+}
+int fwd_walk_lds_bytes(int ng, int tstride, bool rel) { return 32768 + (rel ? 1024 * tstride + 4224 : 0) + (ng ? 3072 + 6272 + 2048 + 32 * tstride : 0) + 16; }
+int fwd_walk_plan(FwdParams& p, int target_wgs) {
+  const int BN = p.B * p.N, NT = (p.S + 31) / 32, U = (NT + 1) / 2;
+  const int ngroups = (BN % 8) == 0 ? 8 : 1, ppg = BN / ngroups;
+  int per_group = target_wgs / ngroups;
+  if (per_group > ppg * U) per_group = ppg * U;
+  if (per_group < ppg) per_group = ppg;
+  p.walk_groups = ngroups; p.walk_nseg = per_group / ppg; p.walk_nhi = per_group % ppg;
+  p.walk_maxseg = p.walk_nseg + (p.walk_nhi ? 1 : 0);
+  return ngroups * per_group;
+}
+size_t fwd_walk_workspace_bytes(int B, int N, int S) { return (size_t)B * N * (((S + 31) / 32 + 1) / 2) * 8 * 66 * sizeof(float); }
 int fwd_win_lds_bytes(int ng, int tstride) { return 65536 + (ng ? (2 * ((ng + 7) / 8) + 1) * 1024 : 0) + 512 * tstride; }
 hipError_t launch_rows_combine(const FwdParams&, bool, hipStream_t) { ++g_launches; g_last_kind = 4; return hipSuccess; }
 hipError_t launch_attn_bwd(const BwdParams& p, int, bool, hipStream_t) {
-  ++g_launches; g_last_kind = 5; g_last_handover = p.ho != nullptr;
+  ++g_launches; g_last_kind = 5; g_last_handover = p.ho != nullptr; g_last_epoch = p.epoch;
   const size_t bn = (size_t)p.B * p.N, slots = bn * p.n_gblk * p.n_chunks;
   inside(p.delta, bn * p.S * 4, "delta");
   inside(p.relfar, bn * p.S * 2 * 4, "relfar");

@@ -1516,14 +1516,9 @@ static hipError_t launch_lean(const BwdParams& p_in, hipStream_t st) {
   p.comb_in_next = ride ? 1 : 0;
   dim3 grid_kv(grid.x + (ride ? (p.pat.ng * p.B * p.N + 3) / 4 : 0));
   if (p.ho) {
-    int win = p.ho_slots <= 5 ? 1 : 0;               // q window of a 128-key workgroup: 4 + ho_slots - 1 <= 8 tiles
-    if (const char* v = std::getenv("MMT_HO_WIN")) win = win && std::atoi(v);
+    const bool win = p.ho_slots <= 5 && !p.ho_per_wave;      // q window of a 128-key workgroup: 4 + ho_slots - 1 <= 8 tiles
     if (win) {
-      static bool granted = false;
-      if (!granted) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_ho_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kHoWinLds);
-        granted = true;
-      }
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_ho_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kHoWinLds);
       hipLaunchKernelGGL(attn_bwd_dkv_ho_kernel<true>, grid_kv, dim3(256), kHoWinLds, st, p);
     } else {
       hipLaunchKernelGGL(attn_bwd_dkv_ho_kernel<false>, grid_kv, dim3(256), 4 * kHoWaveLds, st, p);

@@ -782,18 +782,14 @@ hipError_t launch_attn_fwd_win_bf16(const FwdParams& p, hipStream_t st) {
   const int lds = fwd_win_lds_bytes(p.pat.ng, p.tstride);
   const bool rel = p.R > 0 && p.pat.id_mode == 1;
   const bool drop = p.drop_thresh != 0;
-  auto go = [&](auto kern, int variant) {
-    // the attribute is sticky per kernel: raised once per variant (and again only if a later call needs more).  (All
-    // four variants share one function-pointer type, hence one instantiation of this lambda: the cache is indexed.)
-    static thread_local int granted[4] = {0, 0, 0, 0};
-    if (lds > 64 * 1024 && lds > granted[variant]) {
+  auto go = [&](auto kern) {
+    // the attribute is per kernel and per device: set on every call (host-side, no launch)
+    if (lds > 64 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-      granted[variant] = lds;
-    }
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, p);
   };
-  if (rel) { if (drop) go(attn_fwd_win_bf16_kernel<1, true>, 0); else go(attn_fwd_win_bf16_kernel<1, false>, 1); }
-  else     { if (drop) go(attn_fwd_win_bf16_kernel<0, true>, 2); else go(attn_fwd_win_bf16_kernel<0, false>, 3); }
+  if (rel) { if (drop) go(attn_fwd_win_bf16_kernel<1, true>); else go(attn_fwd_win_bf16_kernel<1, false>); }
+  else     { if (drop) go(attn_fwd_win_bf16_kernel<0, true>); else go(attn_fwd_win_bf16_kernel<0, false>); }
   return hipGetLastError();
 }
 

@@ -23,7 +23,7 @@ struct FwdParams {
   // dropout
   uint32_t drop_thresh;  // 16-bit threshold: keep iff bits16 >= thresh; 0 disables
   uint32_t seed_lo, seed_hi;
-  const unsigned long long* epoch;      // device-resident addend of the seed (mmt_set_step_scalars) or NULL
+  const unsigned long long* epoch;      // device-resident addend of the seed (mmt_attn_desc.dropout_epoch) or NULL
   float inv_keep;
   // kRows
   float* part_o;
@@ -34,7 +34,13 @@ struct FwdParams {
   int perm_1d;        // 1-D ids with R >= 2m+1: table columns permuted, fast path allowed
   int lean_rp;        // lean 2-D path: table width (32 | 64) that holds every id that can contribute
   int rows_only;      // lean band kernel: launch holds the global-row items only (the window kernel produced the band rows)
-  int tstride;        // window kernel: row stride (floats) of the per-wave relative-score table
+  int tstride;        // window / walk kernels: row stride (floats) of the per-wave relative-score table
+  // plane-walk kernel (attn_fwd_walk.hip): runs per plane (walk_nseg, + 1 for the first walk_nhi planes of every XCD
+  // group), XCD groups (8 | 1), partial slots per plane; partials of the global rows [B*N][walk_maxseg][8][66] floats;
+  // arrival counters [B*N] (mmt_attn_desc.sync)
+  int walk_groups, walk_nseg, walk_nhi, walk_maxseg;
+  float* walk_part;
+  unsigned* sync;
   long long* dbg;     // -DMMT_STAMP diagnostic builds only: in-kernel s_memtime stamps (never set in the product)
   int dbg_mode, dbg_sleep;   // -DMMT_STAMP builds only: ablations (1 = no tile loop, 2 = no DMA), start delay of the second resident round
 };
@@ -44,6 +50,10 @@ hipError_t launch_rows_combine(const FwdParams& p, bool bf16, hipStream_t st);
 hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st);   // attn_fwd_band.hip
 hipError_t launch_attn_fwd_win_bf16(const FwdParams& p, hipStream_t st);    // attn_fwd_win.hip
 int fwd_win_lds_bytes(int ng, int tstride);
+hipError_t launch_attn_fwd_walk_bf16(const FwdParams& p, int grid_size, hipStream_t st);   // attn_fwd_walk.hip
+int fwd_walk_lds_bytes(int ng, int tstride, bool rel);
+int fwd_walk_plan(FwdParams& p, int target_wgs);
+size_t fwd_walk_workspace_bytes(int B, int N, int S);
 
 struct BwdParams {
   const void *q, *k, *v, *emb, *bias, *out, *dout;
@@ -87,6 +97,7 @@ struct BwdParams {
   int ho_slots;         // band key tiles per 32-row q block: 2 * ceil(radius / 32) + 1
   int dkv_slots;        // partial slots per (plane, global block) in part_dkv: n_chunks, + 1 with the hand-over (the
                         // band part of the global keys, written by the band key waves)
+  int ho_per_wave;      // hand-over dK/dV pass in its per-wave form even where the window form fits (MMT_TUNE_BWD_HO_PER_WAVE)
   int dq_plane_major;   // dQ pass: plane-major block placement (attn_lean.h) instead of long-items-first + XCD remap
   long long* dbg;    // -DMMT_STAMP diagnostic builds only (see FwdParams)
   int dbg_mode;

@@ -131,14 +131,22 @@ __device__ __forceinline__ int icol(int m, int c) {
 // the 32x32 accumulator-layout values `vals` (16 per lane) are the B operand as they stand
 // (guide: "an accumulator tile as the next MFMA's operand"); X^T fragments come from the
 // wave-private LDS tile through ds_read_b64_tr_b16 (bf16) or straight from registers (f32).
+// Eight f32 -> eight bf16 (round to nearest even) as FOUR v_cvt_pk_bf16_f32: a vector conversion.  Converted element by
+// element, hipcc emits one conversion per value and merges the halves with v_perm_b32 -- 24 instructions for a 16-value
+// fragment where 8 do.  (Not inline asm: an MFMA that reads a register an `asm` has just written gets no hazard padding
+// from the compiler -- a hand-written v_cvt_pk in front of the peeled step's products gave infinities in 4-lane groups.)
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+__device__ __forceinline__ bf16x8 pack8_bf16(const float* v) {
+  const f32x8_t x = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+  return __builtin_convertvector(x, bf16x8);
+}
+
 __device__ __forceinline__ void mma_xt(f32x16& a0, f32x16& a1, const VTile<__bf16>&,
                                        const unsigned char* xlds, const float (&vals)[16], int lane) {
   const int h = lane >> 5, li = lane & 15, cb = (lane >> 4) & 1;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    bf16x8 pf;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) pf[j] = (__bf16)vals[8 * s + j];
+    const bf16x8 pf = pack8_bf16(vals + 8 * s);
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       const int row = 16 * s + 4 * h + (li >> 2);

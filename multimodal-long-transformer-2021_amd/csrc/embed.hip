@@ -31,7 +31,7 @@ struct EmbedParams {
   int S, H, vocab, seg_vocab, patch_start, n_patch;
   float eps, inv_keep;
   uint32_t thresh16, seed_lo, seed_hi;
-  const unsigned long long* epoch;     // device-resident addend of the seed (mmt_set_step_scalars) or NULL
+  const unsigned long long* epoch;     // device-resident addend of the seed (mmt_embed_desc.dropout_epoch) or NULL
   const int *word_ids, *seg_ids, *order, *sorted_ids;   // sorted_ids[i] = word_ids[order[i]]
   const float *word_table, *seg_table, *pos_table, *gamma, *beta, *patch_bias;
   const void* patch;
@@ -331,7 +331,7 @@ void fill_embed(mmt::EmbedParams& p, const mmt_embed_desc* d) {
   if (p.thresh16) {
     p.inv_keep = mmt::dropout_inv_keep(p.thresh16);
     p.seed_lo = (uint32_t)d->dropout_seed; p.seed_hi = (uint32_t)(d->dropout_seed >> 32);
-    p.epoch = mmt::g_dropout_epoch;
+    p.epoch = reinterpret_cast<const unsigned long long*>(d->dropout_epoch);
   }
 }
 

@@ -25,7 +25,7 @@ struct LayerParams {
   int H;
   float eps, inv_keep;
   uint32_t thresh16, seed_lo, seed_hi;
-  const unsigned long long* epoch;     // device-resident addend of the seed (mmt_set_step_scalars) or NULL
+  const unsigned long long* epoch;     // device-resident addend of the seed (mmt_rows_desc.dropout_epoch) or NULL
   const void *a, *b, *c;          // inputs (meaning per kernel)
   const float *p0, *p1, *p2;      // fp32 parameters / statistics
   const float *mean, *rstd;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ prm, flo
                                                     const float* __restrict__ grad_scale, long n_chunks, AdamwParams a,
                                                     const float* __restrict__ hyper) {
   const float gs = grad_scale ? *grad_scale : 1.f;
-  if (hyper) {          // device-resident {lr, bias_correction1, bias_correction2} (mmt_set_step_scalars)
+  if (hyper) {          // device-resident {lr, bias_correction1, bias_correction2} (mmt_adamw_desc.hyper)
     a.lr = hyper[0];
     a.inv_bc1 = 1.f / hyper[1];
     a.inv_sqrt_bc2 = 1.f / sqrtf(hyper[2]);
@@ -521,7 +521,7 @@ void fill(mmt::LayerParams& p, const mmt_rows_desc* d) {
     p.thresh16 = mmt::dropout_thresh16(d->dropout_p);
     p.inv_keep = mmt::dropout_inv_keep(p.thresh16);          // exact keep probability of the 16-bit test
     p.seed_lo = (uint32_t)d->dropout_seed; p.seed_hi = (uint32_t)(d->dropout_seed >> 32);
-    p.epoch = mmt::g_dropout_epoch;
+    p.epoch = reinterpret_cast<const unsigned long long*>(d->dropout_epoch);
   }
 }
 
@@ -699,7 +699,7 @@ int mmt_adamw_step(const mmt_adamw_desc* d, float* param, float* grad, float* ex
   const long n_chunks = d->n >> 10;
   const long blocks = n_chunks < 8192 ? n_chunks : 8192;
   hipLaunchKernelGGL(mmt::adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, (__bf16*)param_bf16, chunk_wd, grad_scale, n_chunks, a, mmt::g_adamw_hyper);
+                     exp_avg_sq, (__bf16*)param_bf16, chunk_wd, grad_scale, n_chunks, a, d->hyper);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_adamw_step: %s", hipGetErrorString(e));
 }

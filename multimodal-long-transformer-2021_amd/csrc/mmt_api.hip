@@ -1,6 +1,7 @@
 // C ABI of the hot path (include/mmt_attn.h): validation, descriptor -> kernel parameter
 // translation, launches on the caller's stream.  No allocation, no synchronisation, no
-// global mutable state (the error message is thread-local).
+// global mutable state (the error message is thread-local; kernel-selection switches and device-resident step
+// scalars travel in the descriptor).
 #include "../../include/mmt_attn.h"
 
 #include <algorithm>
@@ -26,11 +27,6 @@ int fail(int code, const char* fmt, ...) {
   return code;
 }
 }  // namespace mmt
-
-namespace mmt {
-const unsigned long long* g_dropout_epoch = nullptr;
-const float* g_adamw_hyper = nullptr;
-}
 
 namespace {
 using mmt::fail;
@@ -109,6 +105,8 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
   pl.n_rowblk = pl.split_rows ? (d->mask.n_global + 31) / 32 : 0;
   pl.n_chunks = pl.split_rows ? (n_tiles + kChunkTiles - 1) / kChunkTiles : 0;
   pl.fwd_ws = (size_t)d->B * d->N * pl.n_rowblk * pl.n_chunks * (32 * 64 + 64) * sizeof(float);
+  if (pl.split_rows && d->mask.n_global <= 8)      // plane-walk kernel: one partial per (plane, run, global row)
+    pl.fwd_ws = std::max(pl.fwd_ws, mmt::fwd_walk_workspace_bytes(d->B, d->N, d->S));
   // backward: delta, dRel, global-row / global-key partials, dE partials (floats)
   const size_t bn = (size_t)d->B * d->N, Rp = d->R <= 32 ? 32 : 64;
   pl.n_split = (int)std::min<size_t>(256, ((size_t)d->B * d->S + 255) / 256);
@@ -159,7 +157,7 @@ void fill_common(mmt::FwdParams& p, const mmt_attn_desc* d) {
     p.inv_keep = 65536.f / (65536.f - (float)p.drop_thresh);   // exact keep probability of the 16-bit test
     p.seed_lo = (uint32_t)d->dropout_seed;
     p.seed_hi = (uint32_t)(d->dropout_seed >> 32);
-    p.epoch = mmt::g_dropout_epoch;
+    p.epoch = reinterpret_cast<const unsigned long long*>(d->dropout_epoch);
   }
 }
 
@@ -176,12 +174,6 @@ int mmt_write_step_scalars(uint64_t* dropout_epoch, float* adamw_hyper, uint64_t
                                                       (unsigned long long)epoch, lr, bias_correction1, bias_correction2,
                                                       reinterpret_cast<hipStream_t>(stream));
   return e == hipSuccess ? MMT_OK : fail(MMT_E_LAUNCH, "mmt_write_step_scalars: %s", hipGetErrorString(e));
-}
-
-int mmt_set_step_scalars(const uint64_t* dropout_epoch, const float* adamw_hyper) {
-  mmt::g_dropout_epoch = reinterpret_cast<const unsigned long long*>(dropout_epoch);
-  mmt::g_adamw_hyper = adamw_hyper;
-  return MMT_OK;
 }
 
 const char* mmt_last_error(void) { return g_err; }
@@ -234,17 +226,39 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   // window kernel (attn_fwd_win.hip): K / V staged once per workgroup, global keys as a peeled quarter-tile step,
   // rows of up to 16 global tokens by flipped-orientation workgroups of the same launch (no workspace, no combine
   // launch).  Shapes it does not cover, or whose LDS need leaves one workgroup per CU, stay with the per-wave staging
-  // kernel.  MMT_FWD_WIN=0 turns it off, =2 takes it whenever the shape is covered (the tests run both).
-  const char* win_env = std::getenv("MMT_FWD_WIN");          // read per call: the tests switch it
-  const int win_mode = win_env ? std::atoi(win_env) : 1;
+  // kernel.  desc->tuning: MMT_TUNE_FWD_NO_WIN turns it off, MMT_TUNE_FWD_FORCE_WIN takes it whenever the shape is
+  // covered (the tests run both).
+  const int win_mode = (desc->tuning & MMT_TUNE_FWD_NO_WIN) ? 0 : ((desc->tuning & MMT_TUNE_FWD_FORCE_WIN) ? 2 : 1);
   p.tstride = p.pat.id_mode == 0 ? 0 : (2 * p.pat.m + 1 <= 25 ? 26 : 34);
 #ifdef MMT_STAMP
   if (const char* v = std::getenv("MMT_DBG_PTR")) p.dbg = reinterpret_cast<long long*>(std::strtoull(v, nullptr, 0));
   if (const char* v = std::getenv("MMT_DBG_MODE")) p.dbg_mode = std::atoi(v);
   if (const char* v = std::getenv("MMT_DBG_SLEEP")) p.dbg_sleep = std::atoi(v);
 #endif
+  // plane-walk kernel (attn_fwd_walk.hip): persistent workgroups walking runs of row blocks down the band, K / V
+  // sliding through a two-slot LDS ring, the rows of <= 8 global tokens merged from the runs' partials by the last
+  // arriver of each plane (needs the caller's arrival counters, desc->sync).  OPT-IN (MMT_TUNE_FWD_WALK): measured
+  // slower than the window / per-wave kernels at every BASELINE shape -- at per-GPU
+  // batch 4 a plane walk has 12 row blocks per run, and filling / draining the diagonal costs 3 of its 9 super-steps.
+  const bool walk_shape = lean && !p.lean_rp && desc->R <= 32 && p.pat.radius <= 64 && p.pat.ng <= 8 &&
+                          (p.pat.ng == 0 || pl.split_rows) && desc->S > 32;
+  const bool walk_sync = p.pat.ng == 0 || (desc->sync && desc->sync_words >= (uint32_t)(desc->B * desc->N));
+  if (walk_shape && walk_sync && (desc->tuning & MMT_TUNE_FWD_WALK) &&
+      mmt::fwd_walk_lds_bytes(p.pat.ng, p.tstride, p.pat.id_mode != 0) <= 81920) {
+    const int grid = mmt::fwd_walk_plan(p, 2 * 256);      // two resident workgroups per compute unit of an MI355X
+    p.walk_part = reinterpret_cast<float*>(workspace);
+    p.sync = desc->sync;
+    e = mmt::launch_attn_fwd_walk_bf16(p, grid, st);
+    if (e != hipSuccess) return fail(MMT_E_LAUNCH, "plane-walk forward launch: %s", hipGetErrorString(e));
+    return MMT_OK;
+  }
   const bool win_ok = lean && !p.lean_rp && desc->R <= 32 && p.pat.radius <= 64 && p.pat.ng <= 128;
-  const bool win = win_ok && win_mode != 0 && (win_mode == 2 || mmt::fwd_win_lds_bytes(p.pat.ng, p.tstride) <= 81920);
+  // The window kernel's flipped-rows workgroups walk ALL key tiles of their plane (8 waves x S / 256 tiles each): at
+  // S = 8192 one lives longer than the band workgroups of the whole launch take (config 5, g = 8: window 52.7 us,
+  // per-wave 47.1 us per call; at S = 4096: 46.0 against 48.5), so beyond 4096 positions the per-wave kernel keeps
+  // the call unless the window kernel is forced.
+  const bool win = win_ok && win_mode != 0 &&
+                   (win_mode == 2 || (mmt::fwd_win_lds_bytes(p.pat.ng, p.tstride) <= 81920 && (p.pat.ng == 0 || desc->S <= 4096)));
   if (win) {
     // rows of the global tokens: at most 16 -> extra workgroups of the window launch (8 rows each, no workspace, no
     // combine launch); more -> the 32-row items of the per-wave kernel + combine, as a launch of their own
@@ -319,15 +333,16 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     (void)hipMemsetAsync(drel_emb + (size_t)p.Rp * p.N * 64, 0, (size_t)(p.R - p.Rp) * p.N * 64 * sizeof(float), st);
     if (p.drel_bias) (void)hipMemsetAsync(p.drel_bias + (size_t)p.Rp * p.N, 0, (size_t)(p.R - p.Rp) * p.N * sizeof(float), st);
   }
-  if (const char* v = std::getenv("MMT_DQ_PLANE_MAJOR")) p.dq_plane_major = std::atoi(v);
+  p.dq_plane_major = (desc->tuning & MMT_TUNE_BWD_DQ_PLANE_MAJOR) ? 1 : 0;
+  p.ho_per_wave = (desc->tuning & MMT_TUNE_BWD_HO_PER_WAVE) ? 1 : 0;
   // peeled global keys need clipped relative ids only: every peeled key lies beyond the radius, hence beyond max_dist
   p.peel_gkeys = (!dense && pl.split_rows && p.pat.ng <= 8 && (p.pat.id_mode == 0 || (p.perm_1d && p.pat.radius >= p.pat.m))) ? 3 : 0;
   if (!dense && pl.split_rows && p.pat.ng <= 8 && p.lean2d) p.peel_gkeys = 1;      // 2-D ids: the dQ pass's peeled step looks its columns up (the recomputing dK/dV pass keeps its tile visit)
-  if (const char* v = std::getenv("MMT_BWD_PEEL")) p.peel_gkeys &= std::atoi(v);      // bit 0: dQ pass, bit 1: dK/dV pass
+  if (desc->tuning & MMT_TUNE_BWD_NO_PEEL_DQ) p.peel_gkeys &= ~1;       // bit 0: dQ pass, bit 1: dK/dV pass
+  if (desc->tuning & MMT_TUNE_BWD_NO_PEEL_DKV) p.peel_gkeys &= ~2;
   p.dkv_slots = p.n_chunks;
   {   // P / dS hand-over: the dK/dV pass reads what the dQ pass computed (needs the peeled kind of global tokens, if any)
-    int on = 1;
-    if (const char* v = std::getenv("MMT_BWD_HANDOVER")) on = std::atoi(v);
+    const bool on = !(desc->tuning & MMT_TUNE_BWD_NO_HANDOVER);
     const bool lean = desc->dtype == MMT_BF16 && !dense && (p.pat.id_mode == 0 || p.perm_1d || p.lean2d);
     if (on && lean && pl.ho_slots > 0 && (p.pat.ng == 0 || !pl.split_rows || (p.peel_gkeys & 1))) {
       p.ho = reinterpret_cast<unsigned char*>(ws + pl.off_ho);

@@ -19,6 +19,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -99,13 +100,15 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 }
 // Attention-probability dropout: 16 random bits per (b*N+n, q, k); one hash serves the key pair
 // (k & ~1, k | 1); keep iff bits >= thresh16 (restated in oracle/attention.py: dropout_keep_mask).
-// The row base is a full mix32; the per-pair finalizer is ONE multiply round (x ^= x>>16, x *= M, x ^= x>>15):
+// The row base is a full mix32; the per-pair finalizer is ONE multiply round (x ^= x>>16, x = lo24(x) * M24, x ^= x>>15):
 // the pair term is already a product with a large odd constant, and the keep-mask statistics (keep rate, row /
-// column spread, neighbour correlations < 0.003) match the two-round mixer's.  The hash is the biggest single
-// item of a one-id tile's VALU work, and its 32-bit multiplies run at a quarter of the full rate.
+// column spread, neighbour correlations < 0.002: tests/test_oracle_attention.py) match the two-round mixer's.  The
+// hash is the biggest single item of a one-id tile's VALU work; the multiply is the 24-bit one (v_mul_u32_u24, full
+// rate -- a 32-bit v_mul_lo_u32 runs at a quarter of it): the fold before it has already carried bits 24..31 of x into
+// bits 8..15, so the product loses nothing the 32-bit one mixed in.
 constexpr uint32_t kDropPairMul = 0xC2B2AE35u;
 // the dropout seed a kernel works with: the descriptor's, plus the device-resident epoch when one is set
-// (mmt_set_step_scalars; one scalar load per wave)
+// (the descriptor's dropout_epoch; one scalar load per wave)
 struct SeedPair { uint32_t lo, hi; };
 __device__ __forceinline__ SeedPair effective_seed(uint32_t lo, uint32_t hi, const unsigned long long* epoch) {
   if (epoch) {
@@ -121,7 +124,13 @@ __host__ __device__ __forceinline__ uint32_t drop_row_base(uint32_t seed_lo, uin
 // `pair_term` = (k >> 1) * kDropPairMul (the kernels build it with one multiply per tile plus constants)
 __host__ __device__ __forceinline__ uint32_t drop_pair_finish(uint32_t row_base, uint32_t pair_term) {
   uint32_t x = row_base ^ pair_term;
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+  x ^= x >> 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+  x = __umul24(x, 0xeb352du);
+#else
+  x = (x & 0xFFFFFFu) * 0xeb352du;
+#endif
+  x ^= x >> 15;
   return x;
 }
 __host__ __device__ __forceinline__ uint32_t drop_pair_hash(uint32_t row_base, uint32_t k) {

@@ -533,7 +533,7 @@ extern "C" int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, c
   p.tiles_n = N / mmt::kWgTN; p.tiles_m = tiles_m;
   const int tiles = tiles_m * p.tiles_n;
   int split = wgrad_split(tiles, K, tile_m);
-  const bool dma = tile_m == 256 && (K % 64) == 0 && !getenv("MMT_WGRAD_NODMA");
+  const bool dma = tile_m == 256 && (K % 64) == 0;
   const int kq = dma ? 64 : 32;            // rows per main-loop step
   const int kps = (int)(((K + split - 1) / split + kq - 1) / kq * kq);
   split = (int)((K + kps - 1) / kps);

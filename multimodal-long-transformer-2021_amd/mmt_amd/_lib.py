@@ -13,13 +13,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
 LIB_PATH = os.path.join(_HERE, 'libmmt_attn.so')
 
-MMT_ABI_VERSION = 3
+MMT_ABI_VERSION = 4
 MMT_F32, MMT_BF16 = 0, 1
 MMT_IDS_NONE, MMT_IDS_1D, MMT_IDS_2D = 0, 1, 2
 MMT_FLAG_SCALE_BEFORE_ADD = 1
 MMT_FLAG_ACCUM_REL_GRADS = 2
+# mmt_attn_desc.tuning (include/mmt_attn.h): kernel-selection switches; 0 = the library's defaults
+MMT_TUNE_FWD_WALK = 0x01
+MMT_TUNE_FWD_NO_WIN = 0x02
+MMT_TUNE_FWD_FORCE_WIN = 0x04
+MMT_TUNE_BWD_NO_HANDOVER = 0x08
+MMT_TUNE_BWD_HO_PER_WAVE = 0x10
+MMT_TUNE_BWD_NO_PEEL_DQ = 0x20
+MMT_TUNE_BWD_NO_PEEL_DKV = 0x40
+MMT_TUNE_BWD_DQ_PLANE_MAJOR = 0x80
 
-EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_set_step_scalars', 'mmt_write_step_scalars', 'mmt_workspace_bytes', 'mmt_attn_fwd',
+EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_write_step_scalars', 'mmt_workspace_bytes', 'mmt_attn_fwd',
            'mmt_attn_bwd', 'mmt_side_inputs',
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
@@ -32,14 +41,14 @@ class EmbedDesc(ctypes.Structure):
   _fields_ = [('rows', ctypes.c_int64), ('S', ctypes.c_int32), ('H', ctypes.c_int32), ('dtype', ctypes.c_int32),
               ('vocab', ctypes.c_int32), ('seg_vocab', ctypes.c_int32), ('patch_start', ctypes.c_int32),
               ('n_patch', ctypes.c_int32), ('eps', ctypes.c_float), ('dropout_p', ctypes.c_float),
-              ('accumulate', ctypes.c_int32), ('dropout_seed', ctypes.c_uint64)]
+              ('accumulate', ctypes.c_int32), ('dropout_seed', ctypes.c_uint64), ('dropout_epoch', ctypes.c_void_p)]
 
 
 class RowsDesc(ctypes.Structure):
   _fields_ = [('rows', ctypes.c_int64), ('H', ctypes.c_int32), ('dtype', ctypes.c_int32),
               ('eps', ctypes.c_float), ('dropout_p', ctypes.c_float),
               ('dropout_seed', ctypes.c_uint64), ('accumulate', ctypes.c_int32),
-              ('defer_reduce', ctypes.c_int32)]
+              ('defer_reduce', ctypes.c_int32), ('dropout_epoch', ctypes.c_void_p)]
 
 
 class MaskDesc(ctypes.Structure):
@@ -57,14 +66,16 @@ class AttnDesc(ctypes.Structure):
               ('v_stride', ctypes.c_int64 * 3), ('o_stride', ctypes.c_int64 * 3),
               ('scale', ctypes.c_float), ('mask_value', ctypes.c_float),
               ('flags', ctypes.c_uint32), ('dropout_p', ctypes.c_float),
-              ('dropout_seed', ctypes.c_uint64), ('mask', MaskDesc)]
+              ('dropout_seed', ctypes.c_uint64), ('mask', MaskDesc),
+              ('dropout_epoch', ctypes.c_void_p), ('tuning', ctypes.c_uint32), ('sync_words', ctypes.c_uint32),
+              ('sync', ctypes.c_void_p)]
 
 
 class AdamwDesc(ctypes.Structure):
   _fields_ = [('n', ctypes.c_int64), ('lr', ctypes.c_float), ('beta1', ctypes.c_float),
               ('beta2', ctypes.c_float), ('eps', ctypes.c_float), ('bias_correction1', ctypes.c_float),
               ('bias_correction2', ctypes.c_float), ('zero_grad', ctypes.c_int32),
-              ('reserved', ctypes.c_int32)]
+              ('reserved', ctypes.c_int32), ('hyper', ctypes.c_void_p)]
 
 
 class WgradProblem(ctypes.Structure):
@@ -189,8 +200,6 @@ def lib() -> ctypes.CDLL:
                                     ctypes.c_float, vp, vp, vp, ctypes.c_size_t, vp]
   L.mmt_accumulate_grad.restype = ctypes.c_int
   L.mmt_accumulate_grad.argtypes = [vp, vp, ctypes.c_int32, ctypes.c_int64, vp]
-  L.mmt_set_step_scalars.restype = ctypes.c_int
-  L.mmt_set_step_scalars.argtypes = [vp, vp]
   L.mmt_write_step_scalars.restype = ctypes.c_int
   L.mmt_write_step_scalars.argtypes = [vp, vp, ctypes.c_uint64, ctypes.c_float, ctypes.c_float, ctypes.c_float, vp]
   if L.mmt_abi_version() != MMT_ABI_VERSION:

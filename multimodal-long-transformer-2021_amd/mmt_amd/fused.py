@@ -48,7 +48,8 @@ def _desc(x2d: torch.Tensor, eps=1e-12, p=0.0, seed=0) -> _lib.RowsDesc:
     d.dtype = _lib.MMT_BF16
   else:
     raise TypeError(f'fused layer ops support float32 and bfloat16, got {x2d.dtype}')
-  d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), (int(seed) + step_scalars.host_epoch()) & ((1 << 64) - 1)
+  d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), (int(seed) + step_scalars.host_epoch(x2d.device)) & ((1 << 64) - 1)
+  d.dropout_epoch = step_scalars.epoch_ptr(x2d.device) if p else None
   return d
 
 
@@ -550,6 +551,15 @@ def _flush_wgrad_deferred(device) -> None:
         hook(prm)
 
 
+def reset_host_queues() -> None:
+  """Forgets every weight-gradient product a backward pass has queued but not launched, and the pending side-stream
+  joins.  For a step that was ABANDONED half-way (a graph capture that raised inside backward, `graphed.py`): its
+  queued products point at activations of a step that never ran; the retry must not launch them."""
+  _wg_pending.clear()
+  _wg_deferred.clear()
+  _side_pending.clear()
+
+
 def _flush_all_deferred():
   for device in list(_wg_deferred):
     _flush_wgrad_deferred(device)
@@ -721,7 +731,8 @@ class _EmbedAssembleFn(torch.autograd.Function):
     d = _lib.EmbedDesc()
     d.rows, d.S, d.H, d.dtype = B * S, S, H, _dtype_code(out_dtype)
     d.vocab, d.seg_vocab, d.patch_start, d.n_patch = V, st.shape[0], int(patch_start), n_patch
-    d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), (int(seed) + step_scalars.host_epoch()) & ((1 << 64) - 1)
+    d.eps, d.dropout_p, d.dropout_seed = float(eps), float(p), (int(seed) + step_scalars.host_epoch(word_table.device)) & ((1 << 64) - 1)
+    d.dropout_epoch = step_scalars.epoch_ptr(word_table.device) if p else None
     out = torch.empty((B, S, H), dtype=out_dtype, device=word_table.device)
     mean = torch.empty(B * S, dtype=torch.float32, device=out.device)
     rstd = torch.empty_like(mean)

@@ -255,8 +255,10 @@ class _TiedLogitsFn(torch.autograd.Function):
       if (_TIED_DGRAD_SPLIT and dy.is_cuda and dy.dtype == torch.bfloat16 and dy.is_contiguous() and w.is_contiguous()
           and V % 3 == 0 and V >= 8192 and M * w.shape[1] <= (1 << 21)):
         # [M, V] . [V, H] with a long V and a small M x H has 12-64 output tiles for 256 CUs and no split-K solution in
-        # the tuned library set (149 us at 0.32 PFLOP/s at M = 1024): three K slices as one batched product + an fp32 sum
-        # (103 us, tools/tied_dgrad_probe.py); 30522 = 3 x 10174
+        # the tuned library set (149 us at 0.32 PFLOP/s at M = 1024): three K slices as one batched product (103 us,
+        # tools/tied_dgrad_probe.py); 30522 = 3 x 10174.  bmm rounds each slice's partial to bf16 before the three are
+        # added in fp32, so dx carries three roundings of partial sums where the single product has one of the total:
+        # <= 3 bf16 ulps of the largest partial, inside the 3e-2 gradient bar (tests/test_gpu_encoder.py)
         k = V // 3
         dx = torch.bmm(dy.as_strided((3, M, k), (k, V, 1)), w.view(3, k, w.shape[1])).sum(0, dtype=torch.float32).to(dy.dtype)
       else:

@@ -160,8 +160,24 @@ def _strides(t: torch.Tensor):
   return (t.stride(0), t.stride(1), t.stride(2))
 
 
+_SYNC = {}
+
+
+def _sync_words(device, stream_ptr: int, words: int) -> torch.Tensor:
+  """The zero-initialised arrival counters kernels that combine partial results inside one launch need
+  (`mmt_attn_desc.sync`): one buffer per (device, stream) -- calls that share one must be stream-ordered -- created
+  zeroed once; every call leaves it zeroed."""
+  key = (str(device), int(stream_ptr))
+  t = _SYNC.get(key)
+  if t is None or t.numel() < words:
+    if len(_SYNC) > 64:
+      _SYNC.clear()
+    t = _SYNC[key] = torch.zeros(max(int(words), 1024), dtype=torch.int32, device=device)
+  return t
+
+
 def _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_before_add,
-               dropout_p, dropout_seed) -> _lib.AttnDesc:
+               dropout_p, dropout_seed, tuning=0) -> _lib.AttnDesc:
   B, S, N, D = q.shape
   d = _lib.AttnDesc()
   d.B, d.S, d.N, d.D, d.R = B, S, N, D, R
@@ -172,8 +188,12 @@ def _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_bef
   d.mask_value = float(mask_value)
   d.flags = _lib.MMT_FLAG_SCALE_BEFORE_ADD if scale_before_add else 0
   d.dropout_p = float(dropout_p)
-  d.dropout_seed = (int(dropout_seed) + step_scalars.host_epoch()) & ((1 << 64) - 1)
+  d.dropout_seed = (int(dropout_seed) + step_scalars.host_epoch(q.device)) & ((1 << 64) - 1)
+  d.dropout_epoch = step_scalars.epoch_ptr(q.device) if dropout_p else None
   d.mask = (pattern or AttentionPattern(id_mode=_lib.MMT_IDS_NONE)).to_desc(valid_len, q.device)
+  d.tuning = int(tuning)
+  sync = _sync_words(q.device, _stream_ptr(q.device), B * N)
+  d.sync, d.sync_words = sync.data_ptr(), sync.numel()
   return d
 
 
@@ -207,8 +227,9 @@ def relative_attention_forward(q, k, v, rel_emb=None, rel_bias=None, *, att_mask
                                relative_att_ids=None, pattern: Optional[AttentionPattern] = None,
                                valid_len=None, scale=None, mask_value=-10000.0,
                                scale_before_add=False, dropout_p=0.0, dropout_seed=0,
-                               return_lse=True):
-  """Forward only.  Returns (out [B,S,N,D] in q.dtype, lse fp32 [B,N,S])."""
+                               return_lse=True, tuning=0):
+  """Forward only.  Returns (out [B,S,N,D] in q.dtype, lse fp32 [B,N,S]).  `tuning`: `_lib.MMT_TUNE_*` kernel-selection
+  switches (0 = the library's defaults; the parity tests use them to reach every kernel)."""
   R = _check_inputs(q, k, v, rel_emb, rel_bias, att_mask, relative_att_ids, valid_len)
   pattern, att_mask, relative_att_ids = _resolve_pattern(pattern, att_mask, relative_att_ids, valid_len, q)
   dense = att_mask is not None or relative_att_ids is not None
@@ -218,7 +239,7 @@ def relative_attention_forward(q, k, v, rel_emb=None, rel_bias=None, *, att_mask
   out = torch.empty((B, S, N, D), dtype=q.dtype, device=q.device)
   lse = torch.empty((B, N, S), dtype=torch.float32, device=q.device) if return_lse else None
   desc = _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_before_add,
-                    dropout_p, dropout_seed)
+                    dropout_p, dropout_seed, tuning)
   L = _lib.lib()
   ws_bytes = 0 if dense else L.mmt_workspace_bytes(desc)
   ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=q.device)
@@ -260,7 +281,7 @@ def relative_attention_backward(dout, q, k, v, rel_emb, rel_bias, out, lse, *, a
                                 relative_att_ids=None, pattern: Optional[AttentionPattern] = None,
                                 valid_len=None, scale=None, mask_value=-10000.0,
                                 scale_before_add=False, dropout_p=0.0, dropout_seed=0, grads_out=None,
-                                rel_grads_accum=None):
+                                rel_grads_accum=None, tuning=0):
   """Backward of `relative_attention_forward` (recomputes P from `lse`).
 
   Returns (dq, dk, dv, drel_emb, drel_bias); the table gradients are fp32.  `grads_out` may
@@ -282,7 +303,7 @@ def relative_attention_backward(dout, q, k, v, rel_emb, rel_bias, out, lse, *, a
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
   desc = _make_desc(q, k, v, out, R, pattern, valid_len, scale, mask_value, scale_before_add,
-                    dropout_p, dropout_seed)
+                    dropout_p, dropout_seed, tuning)
   if rel_grads_accum is not None and R:
     drel_emb, drel_bias = rel_grads_accum
     for t, shape in ((drel_emb, (R, N, D)), (drel_bias, (R, N))):

@@ -6,6 +6,7 @@ import re
 
 import torch
 
+from . import step_scalars
 from .configs import OptimizerConfig
 
 
@@ -99,6 +100,7 @@ class FusedAdamW:
     for slab in self.slabs:
       d.n = slab['grad'].numel()
       dev = slab['grad'].device
+      d.hyper = step_scalars.hyper_ptr(dev)       # device-resident {lr, bias corrections} of a replayed step, or None
       with torch.cuda.device(dev):
         self._lib.check(L.mmt_adamw_step(
             d, slab['param'].data_ptr(), slab['grad'].data_ptr(), slab['m'].data_ptr(), slab['v'].data_ptr(),

@@ -1,8 +1,10 @@
 """Per-step scalars of a train step -- the step's share of every dropout seed, the learning rate and AdamW's bias
 corrections -- either folded into the descriptors on the host (eager steps) or kept in device memory and read by the
-kernels when they start (`mmt_set_step_scalars`, include/mmt_attn.h), so that a step recorded once as a HIP graph
-(`graphed.GraphedTrainStep`) replays with fresh values.  Both ways give the same numbers: a dropout seed is
-descriptor seed + epoch (mod 2^64) wherever the addition happens.
+kernels when they start, so that a step recorded once as a HIP graph (`graphed.GraphedTrainStep`) replays with fresh
+values.  Both ways give the same numbers: a dropout seed is descriptor seed + epoch (mod 2^64) wherever the addition
+happens.  The device words are named by the descriptors themselves (ABI 4: `dropout_epoch` of mmt_attn_desc /
+mmt_rows_desc / mmt_embed_desc, `hyper` of mmt_adamw_desc, include/mmt_attn.h); the library keeps no registration, so
+what is "active" is this module's business: one `DeviceStepScalars` per device at most.
 
 The reference keeps the same quantities in tf.Variables of its tf.function train step (`optimizer.iterations`, the
 learning-rate schedule evaluated on it; src/tasks/pretraining.py:224-298 runs under `tf.function`)."""
@@ -15,7 +17,12 @@ from . import _lib
 _MASK64 = (1 << 64) - 1
 _EPOCH_MUL = 0x9E3779B97F4A7C15
 _host = {'epoch': 0}
-_device = None             # the active DeviceStepScalars, if any
+_active = {}               # device index -> the active DeviceStepScalars of that device
+
+
+def _index(device) -> int:
+  device = torch.device(device) if device is not None else torch.device('cuda', torch.cuda.current_device())
+  return device.index if device.index is not None else torch.cuda.current_device()
 
 
 def epoch_of(step: int) -> int:
@@ -27,13 +34,26 @@ def set_step(step: int) -> None:
   _host['epoch'] = epoch_of(step)
 
 
-def host_epoch() -> int:
-  """What a descriptor adds to its dropout seed on the host: the step's epoch, or 0 while the kernels add it."""
-  return 0 if _device is not None else _host['epoch']
+def host_epoch(device=None) -> int:
+  """What a descriptor for `device` adds to its dropout seed on the host: the step's epoch, or 0 while the kernels of
+  that device add it themselves."""
+  return 0 if (_active and _index(device) in _active) else _host['epoch']
 
 
-def device_active() -> bool:
-  return _device is not None
+def epoch_ptr(device=None):
+  """Address of the device-resident epoch word for descriptors on `device` (their `dropout_epoch` field), or None."""
+  a = _active.get(_index(device)) if _active else None
+  return None if a is None else a.epoch.data_ptr()
+
+
+def hyper_ptr(device=None):
+  """Address of the device-resident {lr, bias corrections} for mmt_adamw_desc.hyper on `device`, or None."""
+  a = _active.get(_index(device)) if _active else None
+  return None if a is None else a.hyper.data_ptr()
+
+
+def device_active(device=None) -> bool:
+  return bool(_active) and _index(device) in _active
 
 
 class DeviceStepScalars:
@@ -46,18 +66,13 @@ class DeviceStepScalars:
     self.hyper = torch.ones(3, dtype=torch.float32, device=device)
 
   def enable(self) -> None:
-    global _device
-    _lib.check(_lib.lib().mmt_set_step_scalars(self.epoch.data_ptr(), self.hyper.data_ptr()))
-    _device = self
+    _active[_index(self.epoch.device)] = self
 
   def disable(self) -> None:
-    global _device
-    if _device is self:
-      _lib.check(_lib.lib().mmt_set_step_scalars(None, None))
-      _device = None
+    if _active.get(_index(self.epoch.device)) is self:
+      del _active[_index(self.epoch.device)]
 
   def __del__(self):
-    # the library holds raw pointers into these tensors: never let them outlive the registration
     try:
       self.disable()
     except Exception:

@@ -92,54 +92,56 @@ class _TaskBase:
       step = self._auto_step = getattr(self, '_auto_step', 0) + 1
     rank = torch.distributed.get_rank() if (torch.distributed.is_available() and
                                             torch.distributed.is_initialized()) else 0
-    micro = micro_batch_size or getattr(self.task_config, 'micro_batch_size', None)
-    batch_size = inputs['word_ids'].shape[0]
-    micro = micro or batch_size
-    num_small_steps = batch_size // micro
-    if num_small_steps == 0:
-      warnings.warn('per-replica batch smaller than the micro batch: zero micro-steps run '
-                    '(reference behaviour, SURVEY.md App. B q7)')
-    if reducer is not None:
-      reducer.zero_grad()
-    else:
-      optimizer.zero_grad(set_to_none=True)
-    all_loss = torch.zeros((), device=inputs['word_ids'].device)
-    is_t = lambda v: torch.is_tensor(v)
-    for i in range(num_small_steps):
-      # the reference takes the leading `micro` examples, then rotates them to the end
+    try:
+      micro = micro_batch_size or getattr(self.task_config, 'micro_batch_size', None)
+      batch_size = inputs['word_ids'].shape[0]
+      micro = micro or batch_size
+      num_small_steps = batch_size // micro
+      if num_small_steps == 0:
+        warnings.warn('per-replica batch smaller than the micro batch: zero micro-steps run '
+                      '(reference behaviour, SURVEY.md App. B q7)')
       if reducer is not None:
-        reducer.set_armed(i == num_small_steps - 1)
-      fused.set_seed_stream(step, i, rank)
-      sl = slice(i * micro, (i + 1) * micro)
-      small_inputs = {k: (v[sl] if is_t(v) else v) for k, v in inputs.items()}
-      small_labels = {k: v[sl] for k, v in labels.items()}
-      outputs = model(**small_inputs, training=True)
-      loss = self.build_losses(small_labels, outputs, metrics)
-      if metrics:                        # pretraining.py:297 / classification.py:211 (after the gradient in the reference;
-        self.process_metrics(metrics, small_labels, outputs)      # nothing here depends on that order)
-      if self.task_config.scale_loss:   # pretraining.py:286-296: gradient of loss / replicas
-        grad_loss = loss / self.num_replicas
+        reducer.zero_grad()
       else:
-        grad_loss = loss / num_small_steps
-      grad_loss.backward()
-      all_loss = all_loss + (loss / num_small_steps).detach()
-    fused_opt = hasattr(optimizer, 'slabs')          # optimization.FusedAdamW
-    scale = None
-    if reducer is not None:
-      # gradient all-reduce == optimizer.apply_gradients(:273); a fused optimizer applies 1/world itself
-      reducer.finish(defer_mean=fused_opt)
-      if clip_norm:
-        scale = reducer.clip_by_global_norm(clip_norm, apply=not fused_opt)
-      elif fused_opt:
-        scale = reducer.pending_scale_tensor()
-    elif clip_norm:
-      torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
-    if fused_opt:
-      optimizer.step(grad_scale=scale)
-    else:
-      optimizer.step()
-    step_scalars.set_step(0)          # calls outside a train step take their dropout seeds as given
-    return {self.loss: all_loss}
+        optimizer.zero_grad(set_to_none=True)
+      all_loss = torch.zeros((), device=inputs['word_ids'].device)
+      is_t = lambda v: torch.is_tensor(v)
+      for i in range(num_small_steps):
+        # the reference takes the leading `micro` examples, then rotates them to the end
+        if reducer is not None:
+          reducer.set_armed(i == num_small_steps - 1)
+        fused.set_seed_stream(step, i, rank)
+        sl = slice(i * micro, (i + 1) * micro)
+        small_inputs = {k: (v[sl] if is_t(v) else v) for k, v in inputs.items()}
+        small_labels = {k: v[sl] for k, v in labels.items()}
+        outputs = model(**small_inputs, training=True)
+        loss = self.build_losses(small_labels, outputs, metrics)
+        if metrics:                        # pretraining.py:297 / classification.py:211 (after the gradient in the reference;
+          self.process_metrics(metrics, small_labels, outputs)      # nothing here depends on that order)
+        if self.task_config.scale_loss:   # pretraining.py:286-296: gradient of loss / replicas
+          grad_loss = loss / self.num_replicas
+        else:
+          grad_loss = loss / num_small_steps
+        grad_loss.backward()
+        all_loss = all_loss + (loss / num_small_steps).detach()
+      fused_opt = hasattr(optimizer, 'slabs')          # optimization.FusedAdamW
+      scale = None
+      if reducer is not None:
+        # gradient all-reduce == optimizer.apply_gradients(:273); a fused optimizer applies 1/world itself
+        reducer.finish(defer_mean=fused_opt)
+        if clip_norm:
+          scale = reducer.clip_by_global_norm(clip_norm, apply=not fused_opt)
+        elif fused_opt:
+          scale = reducer.pending_scale_tensor()
+      elif clip_norm:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), clip_norm)
+      if fused_opt:
+        optimizer.step(grad_scale=scale)
+      else:
+        optimizer.step()
+      return {self.loss: all_loss}
+    finally:
+      step_scalars.set_step(0)          # calls outside a train step take their dropout seeds as given -- also when the step raised
 
   @torch.no_grad()
   def initialize(self, model):

@@ -67,26 +67,28 @@ def run_experiment(params: configs.ExperimentConfig, mode: str, model_dir: str, 
       graphed_step = graphed.GraphedTrainStep(task, model, optimizer, reducer, opt_cfg, metrics=train_metrics,
                                               clip_norm=opt_cfg.gradient_clip_norm)
     run_experiment.last_step_launch = 'graph' if graphed_step is not None else 'eager'
-    for step in range(start, steps):
-      if graphed_step is not None:
-        out = graphed_step(next(data), step + 1)
-      else:
-        optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, step))
-        out = task.train_step(next(data), model, optimizer, metrics=train_metrics, reducer=reducer,
-                              clip_norm=opt_cfg.gradient_clip_norm, step=step + 1)
-      if step % log_every == 0 or step == steps - 1:
-        loss = float(out[task.loss])
-        logs.append({'step': step, 'loss': loss, 'elapsed_s': time.perf_counter() - t0,
-                     **{k: round(v, 6) for k, v in metrics_lib.results(train_metrics).items()}})
-        metrics_lib.reset(train_metrics)
-        if strategy.rank == 0:
-          print(json.dumps(logs[-1]), flush=True)
-      if ckpt_every and (step + 1) % ckpt_every == 0 and step + 1 < steps:
-        save(step + 1)
-    if steps > start:
-      save(steps)
-    if graphed_step is not None:
-      graphed_step.close()
+    try:
+      for step in range(start, steps):
+        if graphed_step is not None:
+          out = graphed_step(next(data), step + 1)
+        else:
+          optimization.set_learning_rate(optimizer, optimization.learning_rate_at(opt_cfg, step))
+          out = task.train_step(next(data), model, optimizer, metrics=train_metrics, reducer=reducer,
+                                clip_norm=opt_cfg.gradient_clip_norm, step=step + 1)
+        if step % log_every == 0 or step == steps - 1:
+          loss = float(out[task.loss])
+          logs.append({'step': step, 'loss': loss, 'elapsed_s': time.perf_counter() - t0,
+                       **{k: round(v, 6) for k, v in metrics_lib.results(train_metrics).items()}})
+          metrics_lib.reset(train_metrics)
+          if strategy.rank == 0:
+            print(json.dumps(logs[-1]), flush=True)
+        if ckpt_every and (step + 1) % ckpt_every == 0 and step + 1 < steps:
+          save(step + 1)
+      if steps > start:
+        save(steps)
+    finally:
+      if graphed_step is not None:       # also when the loop raised: the device-resident step scalars must not outlive it
+        graphed_step.close()
   if 'eval' in mode:
     vdata = task.build_inputs(params.task.validation_data, device=device, rank=strategy.rank)
     eval_metrics = task.build_metrics(training=False)

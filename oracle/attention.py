@@ -184,7 +184,7 @@ def dropout_keep_mask(B: int, N: int, S: int, p: float, seed: int):
   k = np.arange(S, dtype=np.uint64).reshape(1, 1, S)
   row_base = (_mix32(seed_lo ^ ((bn * np.uint64(0x9E3779B9)) & _M32)) + seed_hi + q * np.uint64(0x85EBCA6B)) & _M32
   x = row_base ^ (((k >> np.uint64(1)) * np.uint64(0xC2B2AE35)) & _M32)
-  x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & _M32; x ^= x >> np.uint64(15)
+  x ^= x >> np.uint64(16); x = ((x & np.uint64(0xFFFFFF)) * np.uint64(0xEB352D)) & _M32; x ^= x >> np.uint64(15)      # (24-bit multiply: csrc/mmt_common.h)
   bits = np.where((k & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
   keep = (bits >= np.uint64(t)).reshape(B, N, S, S)
   return keep, (65536.0 - t) / 65536.0

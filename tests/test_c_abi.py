@@ -25,8 +25,8 @@ def test_header_symbols_are_exported(lib):
   L = lib.lib()
   for name in declared:
     assert hasattr(L, name), name
-  assert L.mmt_abi_version() == 3
-  assert int(re.search(r'#define MMT_ABI_VERSION (\d+)', header).group(1)) == 3
+  assert L.mmt_abi_version() == 4
+  assert int(re.search(r'#define MMT_ABI_VERSION (\d+)', header).group(1)) == 4
 
 
 def test_struct_layout_matches_header(lib):
@@ -39,11 +39,39 @@ def test_struct_layout_matches_header(lib):
   names = re.findall(r'\b(\w+)(?:\[3\])?;', body)
   flat = []
   for line in body.splitlines():
-    m = re.match(r'\s*(?:int32_t|int64_t|float|uint32_t|uint64_t|mmt_mask_desc)\s+([^;]+);', line)
+    m = re.match(r'\s*(?:int32_t|int64_t|float|uint32_t\*?|uint64_t|const uint64_t\*|mmt_mask_desc)\s+([^;]+);', line)
     if m:
       flat += [x.strip().split('[')[0] for x in m.group(1).split(',')]
   assert flat == [f[0] for f in lib.AttnDesc._fields_]
   assert ctypes.sizeof(lib.MaskDesc) == 8 + 7 * 4 + 4 + 8     # pointer + 7 ints (padded to 8) + the ABI-2 index pointer
+
+
+def test_layer_descriptor_layouts_match_the_header(lib):
+  """mmt_layer.h's descriptors (ABI 4 appended the device-resident step scalars to each) against their ctypes mirrors."""
+  header = open(os.path.join(ROOT, 'include', 'mmt_layer.h')).read()
+  for cname, mirror in (('mmt_rows_desc', lib.RowsDesc), ('mmt_embed_desc', lib.EmbedDesc), ('mmt_adamw_desc', lib.AdamwDesc)):
+    body = header[header.index(f'typedef struct {cname}'):header.index(f'}} {cname};')]
+    flat = []
+    for line in body.splitlines():
+      m = re.match(r'\s*(?:int32_t|int64_t|float|uint32_t|uint64_t|const uint64_t\*|const float\*)\s+([^;]+);', line)
+      if m:
+        flat += [x.strip() for x in m.group(1).split(',')]
+    assert flat == [f[0] for f in mirror._fields_], cname
+
+
+def test_the_library_reads_no_environment_variable_and_keeps_no_step_state():
+  """ABI 4: kernel-selection switches and the device-resident step scalars travel in the descriptors.  No getenv in the
+  product build of the library (the -DMMT_STAMP diagnostic build keeps its MMT_DBG_* reads), no registration call."""
+  csrc = os.path.join(ROOT, 'multimodal-long-transformer-2021_amd', 'csrc')
+  for name in os.listdir(csrc):
+    if not name.endswith(('.hip', '.h')):
+      continue
+    src = open(os.path.join(csrc, name)).read()
+    src = re.sub(r'#ifdef MMT_STAMP.*?#endif', '', src, flags=re.S)
+    assert 'getenv' not in src, name
+    assert 'g_dropout_epoch' not in src and 'g_adamw_hyper' not in src, name
+  header = open(os.path.join(ROOT, 'include', 'mmt_attn.h')).read()
+  assert not re.search(r'\bint\s+mmt_set_step_scalars\s*\(', header)
 
 
 def test_integration_document_stub_matches_the_binding(lib):

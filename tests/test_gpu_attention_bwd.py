@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def run_bwd(B, S, N, R, dtype, *, dense, valid=None, radius=1 << 30, g0=0, ng=0, id_mode=1, m=3,
-            P=0, r=0, seed=0, scale_before_add=False, use_bias=True):
+            P=0, r=0, seed=0, scale_before_add=False, use_bias=True, tuning=0):
   import mmt_amd
   q, k, v, emb, bias = attention_inputs(B, S, N, R, seed)
   rng = np.random.default_rng(seed + 100)
@@ -40,7 +40,7 @@ def run_bwd(B, S, N, R, dtype, *, dense, valid=None, radius=1 << 30, g0=0, ng=0,
     pat = mmt_amd.AttentionPattern(local_radius=radius, global_start=g0, n_global=ng, id_mode=id_mode,
                                    max_dist=m, patches_per_row=P, core_layers=r)
     vl = None if valid is None else torch.tensor(valid, dtype=torch.int32, device='cuda:0')
-    out = mmt_amd.relative_attention(tq, tk, tv, te, tb, pattern=pat, valid_len=vl, **kw)
+    out = mmt_amd.relative_attention(tq, tk, tv, te, tb, pattern=pat, valid_len=vl, tuning=tuning, **kw)
   out.backward(dev(dout))
   torch.cuda.synchronize()
   worst = 0.0
@@ -162,7 +162,7 @@ def test_config3_shape_backward_against_oracle():
 
 
 # ---- the three forms of the dK/dV pass on the lean bf16 path ----
-DKV_FORMS = {'recompute': {'MMT_BWD_HANDOVER': '0'}, 'handover-wave': {'MMT_HO_WIN': '0'}, 'handover-window': {}}
+DKV_FORMS = {'recompute': 0x08, 'handover-wave': 0x10, 'handover-window': 0}      # _lib.MMT_TUNE_BWD_NO_HANDOVER / _BWD_HO_PER_WAVE
 
 
 @pytest.mark.parametrize('form', list(DKV_FORMS))
@@ -182,15 +182,13 @@ DKV_FORMS = {'recompute': {'MMT_BWD_HANDOVER': '0'}, 'handover-wave': {'MMT_HO_W
     dict(B=2, S=1200, N=2, R=49, radius=64, g0=1100, ng=8, id_mode=2, m=12, P=33, r=1, valid=[1200, 1111]),
     dict(B=1, S=200, N=2, R=49, radius=20, g0=150, ng=5, id_mode=2, m=12, P=10, r=2),
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'm', 'id_mode')))
-def test_dkv_pass_forms(cfg, form, monkeypatch):
+def test_dkv_pass_forms(cfg, form):
   """The dK/dV pass that recomputes S / dP / P (attn_bwd_dkv_band_bf16_kernel) and the two forms that read the dQ
   pass's probabilities (attn_bwd_dkv_ho_kernel: per-wave tiles, workgroup window), each against the oracle."""
-  for k, v in DKV_FORMS[form].items():
-    monkeypatch.setenv(k, v)
-  run_bwd(dtype=torch.bfloat16, dense=False, **cfg)
+  run_bwd(dtype=torch.bfloat16, dense=False, tuning=DKV_FORMS[form], **cfg)
 
 
-def test_dkv_pass_forms_agree_under_dropout(monkeypatch):
+def test_dkv_pass_forms_agree_under_dropout():
   """Same seed: the hand-over carries the dQ pass's keep decisions (sign bit of the stored probability), the
   recomputing pass regenerates them -- dK / dV agree to bf16 rounding."""
   import mmt_amd
@@ -201,12 +199,8 @@ def test_dkv_pass_forms_agree_under_dropout(monkeypatch):
   kw = dict(pattern=pat, dropout_p=0.25, dropout_seed=77)
   out, lse = mmt_amd.relative_attention_forward(q, k, v, emb, bias, **kw)
   res = {}
-  for form, env in DKV_FORMS.items():
-    for kk in ('MMT_BWD_HANDOVER', 'MMT_HO_WIN'):
-      monkeypatch.delenv(kk, raising=False)
-    for kk, vv in env.items():
-      monkeypatch.setenv(kk, vv)
-    res[form] = [g.float().cpu().numpy() for g in mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, out, lse, **kw)]
+  for form, tuning in DKV_FORMS.items():
+    res[form] = [g.float().cpu().numpy() for g in mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, out, lse, tuning=tuning, **kw)]
   for form in ('handover-wave', 'handover-window'):
     for a, b in zip(res['recompute'], res[form]):
       assert np.abs(a - b).max() <= 3e-2 * max(1.0, np.abs(a).max()), form

@@ -22,7 +22,7 @@ def _to_dev(x, dtype):
 
 
 def run_case(B, S, N, R, dtype, *, dense, valid=None, radius=1 << 30, g0=0, ng=0, id_mode=1, m=3,
-             P=0, r=0, seed=0, scale_before_add=False, use_bias=True):
+             P=0, r=0, seed=0, scale_before_add=False, use_bias=True, tuning=0):
   import mmt_amd
   q, k, v, emb, bias = attention_inputs(B, S, N, R, seed)
   if not use_bias:
@@ -46,7 +46,7 @@ def run_case(B, S, N, R, dtype, *, dense, valid=None, radius=1 << 30, g0=0, ng=0
     pat = mmt_amd.AttentionPattern(local_radius=radius, global_start=g0, n_global=ng, id_mode=id_mode,
                                    max_dist=m, patches_per_row=P, core_layers=r)
     vl = None if valid is None else torch.tensor(valid, dtype=torch.int32, device='cuda:0')
-    out, lse = mmt_amd.relative_attention_forward(tq, tk, tv, te, tb, pattern=pat, valid_len=vl, **kw)
+    out, lse = mmt_amd.relative_attention_forward(tq, tk, tv, te, tb, pattern=pat, valid_len=vl, tuning=tuning, **kw)
   torch.cuda.synchronize()
   tol = F32_TOL if dtype == torch.float32 else BF16_TOL
   got = out.float().cpu().numpy()
@@ -105,7 +105,12 @@ def test_structured_pattern(cfg, dtype):
   run_case(dtype=dtype, dense=False, **cfg)
 
 
-@pytest.mark.parametrize('win', ['0', '2'], ids=['per-wave', 'window'])
+def _fwd_kernels():
+  from mmt_amd import _lib
+  return {'per-wave': _lib.MMT_TUNE_FWD_NO_WIN, 'window': _lib.MMT_TUNE_FWD_FORCE_WIN, 'walk': _lib.MMT_TUNE_FWD_WALK}
+
+
+@pytest.mark.parametrize('kernel', ['per-wave', 'window', 'walk'])
 @pytest.mark.parametrize('cfg', [
     dict(B=2, S=256, N=2, R=32, radius=16, g0=200, ng=8, m=12),
     dict(B=2, S=300, N=2, R=32, radius=64, g0=251, ng=8, m=12, valid=[300, 211]),     # ragged, odd global start
@@ -118,29 +123,28 @@ def test_structured_pattern(cfg, dtype):
     dict(B=1, S=20, N=2, R=9, radius=4, g0=0, ng=1),
     dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'm')))
-def test_both_forward_kernels(cfg, win, monkeypatch):
-  """The per-wave kernel (attn_fwd_band.hip) and the window kernel (attn_fwd_win.hip: shared K / V window, peeled
-  global keys, flipped global rows) on the same cases, each against the oracle; MMT_FWD_WIN picks the kernel
-  (0 = per-wave, 2 = window whenever the shape is covered; the default takes the window kernel when two of its
-  workgroups fit a CU)."""
-  monkeypatch.setenv('MMT_FWD_WIN', win)
-  run_case(dtype=torch.bfloat16, dense=False, **cfg)
+def test_forward_kernels(cfg, kernel):
+  """The per-wave kernel (attn_fwd_band.hip), the window kernel (attn_fwd_win.hip: shared K / V window, peeled
+  global keys, flipped global rows) and the plane-walk kernel (attn_fwd_walk.hip: persistent workgroups, sliding K / V
+  ring, global rows over the walked keys; opt-in) on the same cases, each against the
+  oracle; the descriptor's `tuning` switches pick the kernel."""
+  run_case(dtype=torch.bfloat16, dense=False, tuning=_fwd_kernels()[kernel], **cfg)
 
 
-def test_forward_kernels_share_the_dropout_mask(monkeypatch):
-  """Same seed, same keep decisions: the two bf16 forward kernels agree to output rounding with dropout on (the keep
+def test_forward_kernels_share_the_dropout_mask():
+  """Same seed, same keep decisions: the three bf16 forward kernels agree to output rounding with dropout on (the keep
   mask itself is checked against its restatement in test_gpu_attention_bwd.py)."""
   import mmt_amd
   B, S, N, R = 1, 1024, 2, 32
   q, k, v, emb, bias = (torch.from_numpy(bf16_round(x)).cuda().bfloat16() for x in attention_inputs(B, S, N, R, seed=11))
   pat = mmt_amd.AttentionPattern(local_radius=64, global_start=771, n_global=8, id_mode=1, max_dist=12)
   outs = []
-  for win in ('0', '2'):
-    monkeypatch.setenv('MMT_FWD_WIN', win)
-    o, lse = mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat, dropout_p=0.25, dropout_seed=77)
+  for tuning in _fwd_kernels().values():
+    o, lse = mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat, dropout_p=0.25, dropout_seed=77, tuning=tuning)
     outs.append((o.float().cpu().numpy(), lse.cpu().numpy()))
-  assert np.abs(outs[0][0] - outs[1][0]).max() < BF16_TOL
-  assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-3
+  for other in outs[1:]:
+    assert np.abs(outs[0][0] - other[0]).max() < BF16_TOL
+    assert np.abs(outs[0][1] - other[1]).max() < 1e-3
 
 
 def test_online_softmax_rescale_is_exercised():

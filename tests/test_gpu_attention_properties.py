@@ -6,7 +6,9 @@ global-row items and their combine kernels:
   * softmax rows sum to one          -> V = 1 gives O = 1 (any mask, any relative term)
   * the output is linear in V        -> O(V1 + V2) = O(V1) + O(V2)
   * (batch, head) planes are independent and the kernels are deterministic -> permuting planes permutes the
-    outputs BIT-EXACTLY; two runs are bit-identical (forward and backward)
+    outputs BIT-EXACTLY (band rows; the 8 global tokens' rows to output rounding: the plane-walk kernel merges them
+    from as many partial sums as the plane has runs, 10 or 11 by the plane's place in the grid); two runs are
+    bit-identical (forward and backward)
   * dO = 1 gives dV[k,:] = sum_q P[q,k], so sum_k dV[k,d] = S; and sum_k dS[q,k] = 0 for every row, so the
     relative-bias gradient sums to zero over the ids (all 1-D ids are inside the table).
 """
@@ -66,8 +68,14 @@ def test_planes_are_independent_and_runs_are_bit_identical():
   perm_n = torch.randperm(N, device='cuda', generator=torch.Generator(device='cuda').manual_seed(3))
   qp, kp, vp = (t[perm_b][:, :, perm_n].contiguous() for t in (q, k, v))
   op, lsep = mmt_amd.relative_attention_forward(qp, kp, vp, emb[:, perm_n].contiguous(), bias[:, perm_n].contiguous(), **kw)
-  assert torch.equal(op, o[perm_b][:, :, perm_n])
-  assert torch.equal(lsep, lse[perm_b][:, perm_n])
+  want, want_lse = o[perm_b][:, :, perm_n], lse[perm_b][:, perm_n]
+  band = torch.ones(S, dtype=torch.bool, device='cuda')
+  band[3971:3979] = False                                   # the global tokens' rows
+  assert torch.equal(op[:, band], want[:, band])
+  assert torch.equal(lsep[:, :, band], want_lse[:, :, band])
+  # rows of the global tokens: the same sums in a partition that depends on the plane's place in the grid
+  assert float((op[:, ~band].float() - want[:, ~band].float()).abs().max()) < 2e-3
+  assert float((lsep[:, :, ~band] - want_lse[:, :, ~band]).abs().max()) < 1e-5
   dout = torch.randn_like(o)
   g1 = mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, o, lse, **kw)
   g2 = mmt_amd.relative_attention_backward(dout, q, k, v, emb, bias, o, lse, **kw)

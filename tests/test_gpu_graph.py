@@ -1,5 +1,5 @@
 """The train step recorded as a HIP graph (mmt_amd/graphed.py) and the device-resident step scalars behind it
-(mmt_set_step_scalars): same numbers as the eager step -- the kernels are deterministic and a dropout seed is
+(named by the descriptors since ABI 4: `dropout_epoch`, `mmt_adamw_desc.hyper`): same numbers as the eager step -- the kernels are deterministic and a dropout seed is
 descriptor seed + epoch wherever the addition happens."""
 import numpy as np
 import pytest
@@ -137,6 +137,86 @@ def test_a_step_that_cannot_be_recorded_stays_eager(monkeypatch):
   l5 = float(step()['loss'])
   assert np.isfinite(l4) and np.isfinite(l5) and gs.optimizer.t == 5
   step.close()
+
+
+def _twin_steps(B=4, micro=2):
+  """Two identically initialised (task, model, optimizer) sets behind GraphedTrainStep objects -- the second one never
+  records (all eager) -- plus the resident batch."""
+  import bench
+  from mmt_amd import benchmarks
+  cfg = dict(bench.config3(), S=256, P=14, B=B, g0=2 + 14 * 14, ng=8)
+  out = []
+  for _ in range(2):
+    step = benchmarks.make_train_step_bench(cfg, torch.device('cuda:0'), 0, 1, dtype=torch.bfloat16, graph=True)[0]
+    cells = [c.cell_contents for c in step.__closure__]
+    gs = [c for c in cells if hasattr(c, '_record')][0]
+    batch = [c for c in cells if isinstance(c, tuple) and len(c) == 2 and isinstance(c[0], dict)][0]
+    gs.task.task_config.micro_batch_size = micro
+    gs.static_inputs = False
+    out.append((gs, batch))
+  out[1][0].eager_left = 1 << 62
+  return out
+
+
+def test_a_batch_that_does_not_fit_the_graph_runs_eagerly():
+  """A short batch in the middle of a graphed run (the last batch of an epoch): that step runs eagerly with the step's
+  own dropout masks and learning rate, the replays before and after are untouched -- losses and parameters equal the
+  all-eager twin's.  (Copied into the recorded buffers it would broadcast and train on duplicated rows.)"""
+  (gs, batch), (eg, batch2) = _twin_steps()
+  short = lambda b: tuple({k: (v[:2] if torch.is_tensor(v) else v) for k, v in tree.items()} for tree in b)
+  from mmt_amd import step_scalars
+  losses = {0: [], 1: []}
+  for step in range(1, 10):          # the two models take turns in ONE process: neither may see the other's step scalars
+    for i, (st, bt) in enumerate(((gs, batch), (eg, batch2))):
+      b = short(bt) if step == 6 else bt
+      if i == 0 and step == 6:
+        with pytest.warns(UserWarning, match='does not match the recorded HIP graph'):
+          losses[i].append(float(st(b, step)['loss']))
+      else:
+        losses[i].append(float(st(b, step)['loss']))
+      assert not step_scalars.device_active()       # device-resident scalars are named only while a step is recorded
+  assert gs.graph is not None and eg.graph is None
+  assert losses[0] == losses[1]
+  assert torch.equal(torch.cat([s['param'] for s in gs.optimizer.slabs]), torch.cat([s['param'] for s in eg.optimizer.slabs]))
+  assert gs.optimizer.param_groups[0]['lr'] == eg.optimizer.param_groups[0]['lr']      # the host's copy follows the schedule
+  # a batch with a key missing, or another constant, is refused the same way
+  assert not gs._same_signature(({k: v for k, v in batch[0].items() if k != 'word_ids'}, batch[1]))
+  gs.close(); eg.close()
+
+
+def test_a_capture_that_fails_inside_backward_leaves_no_queued_work(monkeypatch):
+  """The recording raises in the middle of backward (after weight-gradient products of the upper layers were queued
+  and the reducer had counted gradients): the step object warns, resets the host-side queues and the reducer, and the
+  eager retry and every later step equal the all-eager twin's."""
+  from mmt_amd import fused, ops, step_scalars
+  (gs, batch), (eg, batch2) = _twin_steps()
+  real = ops.relative_attention_backward
+  seen = {'queued': 0, 'ready': 0, 'calls': 0, 'raised': 0}
+
+  def flaky(*a, **k):
+    if torch.cuda.is_current_stream_capturing() and not seen['raised']:
+      seen['calls'] += 1
+      if seen['calls'] == 2:            # the second attention backward of the pass: layers above it have run theirs
+        seen['raised'] = 1
+        seen['queued'] = sum(len(e[1]) for e in list(fused._wg_pending.values()) + list(fused._wg_deferred.values()))
+        seen['ready'] = len(gs.reducer._ready) + sum(1 for p in gs.model.parameters() if getattr(p, '_mmt_grad_deferred', False))
+        raise RuntimeError('not capturable (test)')
+    return real(*a, **k)
+  monkeypatch.setattr(ops, 'relative_attention_backward', flaky)
+  la, lb = [], []
+  for step in range(1, 8):
+    if step == 4:
+      with pytest.warns(UserWarning, match='not recorded as a HIP graph'):
+        la.append(float(gs(batch, step)['loss']))
+    else:
+      la.append(float(gs(batch, step)['loss']))
+    lb.append(float(eg(batch2, step)['loss']))
+  assert seen['raised'] == 1 and seen['queued'] + seen['ready'] > 0      # the failure did strand host-side state of the abandoned pass
+  assert gs.graph is None and not step_scalars.device_active()
+  assert not fused._wg_pending and not fused._wg_deferred
+  assert la == lb
+  assert torch.equal(torch.cat([s['param'] for s in gs.optimizer.slabs]), torch.cat([s['param'] for s in eg.optimizer.slabs]))
+  gs.close(); eg.close()
 
 
 def test_classification_trainer_loop_graphed_equals_eager(tmp_path, monkeypatch):

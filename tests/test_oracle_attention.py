@@ -128,3 +128,25 @@ def test_backward_finite_differences():
       n = a.copy(); n[idx] -= eps
       fd = (loss(**{key: p}) - loss(**{key: n})) / (2 * eps)
       assert abs(fd - g[name][idx]) < 1e-6 * max(1.0, abs(fd)), (name, idx, fd, g[name][idx])
+
+
+def test_dropout_keep_mask_statistics():
+  """The attention-dropout keep mask (counter hash of (seed, plane, q, k >> 1), 16 bits per element, 24-bit multiply in
+  the per-pair finisher: csrc/mmt_common.h, restated in oracle.attention.dropout_keep_mask): keep rate within 3e-4 of
+  1 - p, row / column keep-rate spread binomial, neighbour correlations (along k, along q, diagonals, across planes,
+  across a tile) below 2.5e-3 -- for several seeds, including one with a step epoch added."""
+  from oracle import attention as oa
+  for p in (0.1, 0.25):
+    for seed in (12345, 0xDEADBEEF12345678, (77 * 0x9E3779B97F4A7C15 + 5) & ((1 << 64) - 1)):
+      keep, kp = oa.dropout_keep_mask(3, 2, 768, p, seed)
+      m = keep.reshape(6, 768, 768).astype(np.float64)
+      assert abs(m.mean() - kp) < 6e-4 and abs(kp - (1 - p)) < 1e-4
+      c = lambda a, b: abs(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]))
+      assert c(m[:, :, :-1], m[:, :, 1:]) < 2.5e-3          # the two elements of a pair, and neighbouring pairs
+      assert c(m[:, :, :-2], m[:, :, 2:]) < 2.5e-3
+      assert c(m[:, :-1], m[:, 1:]) < 2.5e-3                # neighbouring rows
+      assert c(m[:-1], m[1:]) < 2.5e-3                      # neighbouring planes
+      assert c(m[:, :-1, :-1], m[:, 1:, 1:]) < 2.5e-3 and c(m[:, :-1, 1:], m[:, 1:, :-1]) < 2.5e-3
+      assert c(m[:, :, :-64], m[:, :, 64:]) < 2.5e-3 and c(m[:, :-32], m[:, 32:]) < 2.5e-3
+      sd = np.sqrt(p * (1 - p) / 768)
+      assert abs(m.mean(2).std() - sd) < 0.15 * sd and abs(m.mean(1).std() - sd) < 0.15 * sd
