@@ -134,7 +134,9 @@ int main(void) {
       CHECK(mmt_attn_fwd(&dw, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, w2, need, NULL) == MMT_OK && g_last_kind == 3);
       dw.sync_words = 48;
       CHECK(mmt_attn_fwd(&dw, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, w2, need, NULL) == MMT_OK && g_last_kind == 8);
-      dw.tuning = 0;
+      dw.tuning = MMT_TUNE_FWD_PWIN;                             /* likewise opt-in: the sliding-window kernel */
+      CHECK(mmt_attn_fwd(&dw, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, w2, need, NULL) == MMT_OK && g_last_kind == 9);
+      dw.tuning = 0;                                             /* the default stays the window kernel, counters or not */
       CHECK(mmt_attn_fwd(&dw, dummy, dummy, dummy, dummy, NULL, NULL, NULL, dummy, NULL, w2, need, NULL) == MMT_OK && g_last_kind == 3);
       free(w2);
       g_ws_lo = ws; g_ws_hi = ws + mmt_workspace_bytes(&da) + 1;

@@ -10,7 +10,7 @@ extern "C" {
 const unsigned char* g_ws_lo = nullptr;
 const unsigned char* g_ws_hi = nullptr;
 int g_launches = 0;
-int g_last_kind = 0;   // 1 fwd general, 2 fwd band, 3 fwd window, 4 rows combine, 5 bwd, 6 side inputs, 7 step scalars, 8 fwd plane walk
+int g_last_kind = 0;   // 1 fwd general, 2 fwd band, 3 fwd window, 4 rows combine, 5 bwd, 6 side inputs, 7 step scalars, 8 fwd plane walk, 9 fwd sliding window
 int g_last_handover = 0;   // the last backward asked for the P hand-over
 const void* g_last_epoch = nullptr;   // the device epoch word the last attention launch was given
 }
@@ -44,6 +44,25 @@ hipError_t launch_attn_fwd_walk_bf16(const FwdParams& p, int grid, hipStream_t) 
     std::fprintf(stderr, "asan driver: inconsistent plane-walk plan\n"); std::abort();
   }
   return hipSuccess;
+}
+hipError_t launch_attn_fwd_pwin_bf16(const FwdParams& p, int grid, hipStream_t) {
+  ++g_launches; g_last_kind = 9; g_last_epoch = p.epoch;
+  const int nqb = (p.S + 127) / 128, total = p.B * p.N * nqb;
+  if (grid <= 0 || p.pw_walk < 1 || (long)grid * p.pw_walk < total || (long)(grid - 1) * p.pw_walk >= total) { std::fprintf(stderr, "asan driver: inconsistent sliding-window plan\n"); std::abort(); }
+  if (p.pat.ng > 0) inside(p.walk_part, ((size_t)grid * (8 * 34 + 4 * 784) + (size_t)p.B * p.N * p.walk_maxseg * 4 * 8 * 66) * 4, "pwin workspace");
+  return hipSuccess;
+}
+int fwd_pwin_plan(FwdParams& p, int target_wgs) {
+  const int nqb = (p.S + 127) / 128, total = p.B * p.N * nqb;
+  int walk = (total + target_wgs - 1) / target_wgs; if (walk < 1) walk = 1;
+  p.pw_walk = walk; p.walk_maxseg = (nqb + walk - 1) / walk + 1;
+  return (total + walk - 1) / walk;
+}
+size_t fwd_pwin_workspace_bytes(int B, int N, int S, int target_wgs) {
+  const int nqb = (S + 127) / 128, total = B * N * nqb;
+  const int walk = (total + target_wgs - 1) / target_wgs < 1 ? 1 : (total + target_wgs - 1) / target_wgs;
+  const size_t grid = (size_t)(total + walk - 1) / walk, maxseg = (size_t)(nqb + walk - 1) / walk + 1;
+  return (grid * (8 * 34 + 4 * 784) + (size_t)B * N * maxseg * 4 * 8 * 66) * sizeof(float);
 }
 int fwd_walk_lds_bytes(int ng, int tstride, bool rel) { return 32768 + (rel ? 1024 * tstride + 4224 : 0) + (ng ? 3072 + 6272 + 2048 + 32 * tstride : 0) + 16; }
 int fwd_walk_plan(FwdParams& p, int target_wgs) {

@@ -39,6 +39,7 @@ struct FwdParams {
   // group), XCD groups (8 | 1), partial slots per plane; partials of the global rows [B*N][walk_maxseg][8][66] floats;
   // arrival counters [B*N] (mmt_attn_desc.sync)
   int walk_groups, walk_nseg, walk_nhi, walk_maxseg;
+  int pw_walk;        // sliding-window kernel (attn_fwd_pwin.hip): consecutive 128-row blocks per workgroup
   float* walk_part;
   unsigned* sync;
   long long* dbg;     // -DMMT_STAMP diagnostic builds only: in-kernel s_memtime stamps (never set in the product)
@@ -54,6 +55,9 @@ hipError_t launch_attn_fwd_walk_bf16(const FwdParams& p, int grid_size, hipStrea
 int fwd_walk_lds_bytes(int ng, int tstride, bool rel);
 int fwd_walk_plan(FwdParams& p, int target_wgs);
 size_t fwd_walk_workspace_bytes(int B, int N, int S);
+hipError_t launch_attn_fwd_pwin_bf16(const FwdParams& p, int grid_size, hipStream_t st);   // attn_fwd_pwin.hip
+int fwd_pwin_plan(FwdParams& p, int target_wgs);
+size_t fwd_pwin_workspace_bytes(int B, int N, int S, int target_wgs);
 
 struct BwdParams {
   const void *q, *k, *v, *emb, *bias, *out, *dout;

@@ -105,8 +105,10 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
   pl.n_rowblk = pl.split_rows ? (d->mask.n_global + 31) / 32 : 0;
   pl.n_chunks = pl.split_rows ? (n_tiles + kChunkTiles - 1) / kChunkTiles : 0;
   pl.fwd_ws = (size_t)d->B * d->N * pl.n_rowblk * pl.n_chunks * (32 * 64 + 64) * sizeof(float);
-  if (pl.split_rows && d->mask.n_global <= 8)      // plane-walk kernel: one partial per (plane, run, global row)
+  if (pl.split_rows && d->mask.n_global <= 8) {    // plane-walk / sliding-window kernels: partials of the global rows per run
     pl.fwd_ws = std::max(pl.fwd_ws, mmt::fwd_walk_workspace_bytes(d->B, d->N, d->S));
+    pl.fwd_ws = std::max(pl.fwd_ws, mmt::fwd_pwin_workspace_bytes(d->B, d->N, d->S, 2 * 256));
+  }
   // backward: delta, dRel, global-row / global-key partials, dE partials (floats)
   const size_t bn = (size_t)d->B * d->N, Rp = d->R <= 32 ? 32 : 64;
   pl.n_split = (int)std::min<size_t>(256, ((size_t)d->B * d->S + 255) / 256);
@@ -251,6 +253,24 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     e = mmt::launch_attn_fwd_walk_bf16(p, grid, st);
     if (e != hipSuccess) return fail(MMT_E_LAUNCH, "plane-walk forward launch: %s", hipGetErrorString(e));
     return MMT_OK;
+  }
+  // sliding-window kernel (attn_fwd_pwin.hip): the window kernel made persistent -- <= 512 resident workgroups walking
+  // consecutive 128-row blocks, four new K / V tiles per block by LDS-DMA, the next block's Q under the merge, the rows
+  // of <= 8 global tokens by the pairs' second waves beside the table build and merged by the plane's last arriver.
+  // OPT-IN (MMT_TUNE_FWD_PWIN): correct on every case of the forward tests, measured slower than the window kernel
+  // (config 3: 41.9 vs 37.9 us without global tokens, 96 vs 43 us with 8; stamps in profiles/r04_pwin_stamps_*.txt,
+  // DESIGN.md section 4, round 4).
+  const bool pwin_shape = lean && !p.lean_rp && desc->R <= 32 && p.pat.radius <= 64 && p.pat.ng <= 8 && p.tstride <= 26 &&
+                          (p.pat.ng == 0 || (pl.split_rows && p.pat.radius > 32));
+  if (pwin_shape && walk_sync && (desc->tuning & MMT_TUNE_FWD_PWIN)) {
+    const int grid = mmt::fwd_pwin_plan(p, 2 * 256);
+    if (p.pat.ng == 0 || p.walk_maxseg <= 51) {            // (the last arriver's merge keeps a (max, sum) pair per partial in LDS)
+      p.walk_part = reinterpret_cast<float*>(workspace);
+      p.sync = desc->sync;
+      e = mmt::launch_attn_fwd_pwin_bf16(p, grid, st);
+      if (e != hipSuccess) return fail(MMT_E_LAUNCH, "sliding-window forward launch: %s", hipGetErrorString(e));
+      return MMT_OK;
+    }
   }
   const bool win_ok = lean && !p.lean_rp && desc->R <= 32 && p.pat.radius <= 64 && p.pat.ng <= 128;
   // The window kernel's flipped-rows workgroups walk ALL key tiles of their plane (8 waves x S / 256 tiles each): at

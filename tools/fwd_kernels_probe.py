@@ -14,13 +14,13 @@ q, k, v = (torch.randn(B, S, N, D, device='cuda', generator=g).to(torch.bfloat16
 emb = (torch.randn(R, N, D, device='cuda', generator=g) * 0.02).to(torch.bfloat16)
 bias = (torch.randn(R, N, device='cuda', generator=g) * 0.02).to(torch.bfloat16)
 pat = mmt_amd.AttentionPattern(local_radius=cfg['radius'], global_start=cfg['g0'], n_global=cfg['ng'], id_mode=1, max_dist=cfg['m'])
-kinds = {'default': 0, 'walk': _lib.MMT_TUNE_FWD_WALK, 'window': _lib.MMT_TUNE_FWD_FORCE_WIN, 'per-wave': _lib.MMT_TUNE_FWD_NO_WIN}
+kinds = {'default': 0, 'sliding window': _lib.MMT_TUNE_FWD_PWIN, 'window': _lib.MMT_TUNE_FWD_FORCE_WIN, 'walk': _lib.MMT_TUNE_FWD_WALK, 'per-wave': _lib.MMT_TUNE_FWD_NO_WIN}
 call = lambda t: mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat, dropout_p=pdrop, dropout_seed=12345, tuning=t)
 outs = {n: call(t) for n, t in kinds.items()}
 torch.cuda.synchronize()
 ref = outs['per-wave']
 for n, (o, l) in outs.items():
-  print(f'{n:9s} max|out - per-wave| = {float((o.float() - ref[0].float()).abs().max()):.3e}   max|lse - per-wave| = {float((l - ref[1]).abs().max()):.3e}'
+  print(f'{n:26s} max|out - per-wave| = {float((o.float() - ref[0].float()).abs().max()):.3e}   max|lse - per-wave| = {float((l - ref[1]).abs().max()):.3e}'
         f'   finite: {bool(torch.isfinite(o.float()).all())}', flush=True)
 times = {n: [] for n in kinds}
 for rnd in range(5):
@@ -35,4 +35,4 @@ for rnd in range(5):
     torch.cuda.synchronize()
     times[n].append(e0.elapsed_time(e1) / 20 * 1e3)
 for n, ts in times.items():
-  print(f'{n:9s} us per call: median {sorted(ts)[len(ts) // 2]:.1f}  min {min(ts):.1f}  all {[round(x, 1) for x in ts]}')
+  print(f'{n:26s} us per call: median {sorted(ts)[len(ts) // 2]:.1f}  min {min(ts):.1f}  all {[round(x, 1) for x in ts]}')
