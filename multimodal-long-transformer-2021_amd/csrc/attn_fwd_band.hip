@@ -17,18 +17,18 @@
 namespace mmt {
 
 template <int Rp, int REL>        // REL: 0 no relative term, 1 = 1-D ids (permuted table), 2 = 2-D ids (columns in id order)
-__global__ __launch_bounds__(256, (Rp == 64 && REL == 2) ? 2 : 3) void attn_fwd_band_bf16_kernel(const FwdParams p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_band_bf16_kernel(const FwdParams p) {
   using T = __bf16;
   constexpr bool HAS_REL = REL != 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
-  constexpr int kWaveBytes = WaveLds<T, Rp>::kBytes + 4096;      // T table, V tile, K tile
-  unsigned char* wl = smem + wave * kWaveBytes;
-  float* tab = reinterpret_cast<float*>(wl);
-  unsigned char* vlds = wl + WaveLds<T, Rp>::kTBytesAligned;
-  unsigned char* klds = vlds + 4096;
+  constexpr int kWaveBytes = WaveLds<T, Rp>::kBytes;             // T table, one tile buffer: the K tile, then (its row
+  unsigned char* wl = smem + wave * kWaveBytes;                  // fragments read) the V tile -- LDS serves a wave's
+  float* tab = reinterpret_cast<float*>(wl);                     // accesses in order, so the two never meet, and three
+  unsigned char* vlds = wl + WaveLds<T, Rp>::kTBytesAligned;     // workgroups fit a compute unit at the 64-wide table too
+  unsigned char* klds = vlds;
   int* lut = reinterpret_cast<int*>(smem + 4 * kWaveBytes) + wave * ((lut2d_entries(p.pat) + 15) & ~15);   // REL == 2: wave-private
 
   // ---- work item ------------------------------------------------------------------------
@@ -168,18 +168,28 @@ __global__ __launch_bounds__(256, (Rp == 64 && REL == 2) ? 2 : 3) void attn_fwd_
 
   for (int it = 0; it < n_it; ++it) {
     const int k0 = tile_at(it) * 32;
-    // V rows of this tile -> wave-private LDS (read back transposed after the softmax)
+    // K rows of this tile -> the wave-private LDS tile, row fragments back; then the V rows into the same tile (read back
+    // transposed after the softmax)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int ci = lane + 64 * u, row = ci >> 3, ch = ci & 7;
       const int off = row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
-      *reinterpret_cast<bf16x8*>(vlds + off) = vt[u];
       *reinterpret_cast<bf16x8*>(klds + off) = kt[u];
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     Frag<T> kf;
     frag_from_tile(kf, klds, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ci = lane + 64 * u, row = ci >> 3, ch = ci & 7;
+      const int off = row * 128 + ((((ch >> 2) ^ ((row >> 1) & 1))) << 6) + (ch & 3) * 16;
+      *reinterpret_cast<bf16x8*>(vlds + off) = vt[u];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     f32x16 c = {0};
     c = mma_rows(kf, qf, c);     // S^T [key x q]
     if (it + 1 < n_it) {         // prefetch the next tile under this tile's math
@@ -397,9 +407,9 @@ hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st) {
   if (rel == 2) {                    // 2-D ids: table width chosen by the host (lean_rp), one look-up table per wave
     const int n2 = 2 * p.pat.r + 3, lut_bytes = 4 * 4 * ((n2 * n2 + 15) & ~15);
     if (p.lean_rp == 32) {
-      hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, 2>), grid, dim3(256), 4 * (WaveLds<__bf16, 32>::kBytes + 4096) + lut_bytes, st, p);
+      hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, 2>), grid, dim3(256), 4 * (WaveLds<__bf16, 32>::kBytes) + lut_bytes, st, p);
     } else {
-      const int lds = 4 * (WaveLds<__bf16, 64>::kBytes + 4096) + lut_bytes;
+      const int lds = 4 * (WaveLds<__bf16, 64>::kBytes) + lut_bytes;
       if (lds > 64 * 1024)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_band_bf16_kernel<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, 2>), grid, dim3(256), lds, st, p);
@@ -407,11 +417,11 @@ hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st) {
     return hipGetLastError();
   }
   if (p.R <= 32) {
-    const int lds = 4 * (WaveLds<__bf16, 32>::kBytes + 4096);
+    const int lds = 4 * (WaveLds<__bf16, 32>::kBytes);
     if (rel) hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, 1>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<32, 0>), grid, dim3(256), lds, st, p);
   } else {
-    const int lds = 4 * (WaveLds<__bf16, 64>::kBytes + 4096);
+    const int lds = 4 * (WaveLds<__bf16, 64>::kBytes);
     if (rel) hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, 1>), grid, dim3(256), lds, st, p);
     else hipLaunchKernelGGL((attn_fwd_band_bf16_kernel<64, 0>), grid, dim3(256), lds, st, p);
   }

@@ -119,7 +119,7 @@ class GradientBucketReducer:
         # leave compute units to the RCCL kernels that run under backward (csrc/wgrad_gemm.hip)
         from . import _lib
         _lib.lib().mmt_wgrad_set_cu_budget(int(os.environ.get('MMT_WGRAD_CUS', '224')))
-        _lib.lib().mmt_ffn_set_cu_budget(int(os.environ.get('MMT_WGRAD_CUS', '224')))
+        _lib.lib().mmt_ffn_set_cu_budget(int(os.environ.get('MMT_FFN_CUS', '224')))
       for p in self.params:
         p.register_post_accumulate_grad_hook(self._on_grad_ready)
         # Kernels that add a gradient straight into `.grad` (weight-gradient GEMM, fused-layer column
@@ -165,10 +165,7 @@ class GradientBucketReducer:
       self._launch(gi)
 
   def _launch(self, gi):
-    # weight gradients may still be in flight on fused's side stream: the collective is ordered against
-    # the current stream, so that one has to wait for them first
-    from . import fused
-    fused.wait_side_streams()
+    # (every gradient kernel runs on the current stream, and so is the collective ordered: nothing to wait for)
     self._handles.append(dist.all_reduce(self.buckets[gi], op=dist.ReduceOp.SUM, async_op=True))
 
   def finish(self, defer_mean: bool = False):

@@ -7,7 +7,6 @@ and their gradients come back fp32 straight from the kernels.
 """
 from __future__ import annotations
 
-import os
 
 from typing import Optional
 
@@ -126,13 +125,10 @@ class _LayerNormFn(torch.autograd.Function):
       dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
     d = _desc(x2, ctx.eps)
     d.accumulate = int(direct)
-    d.defer_reduce = int(direct and side_stream_ok(gamma_p, beta_p))
     ws = _ws(d, x2)
     with torch.cuda.device(x2.device):
       _lib.check(_lib.lib().mmt_ln_bwd(d, _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg),
                                        _p(db), _p(ws), ws.numel(), _stream(x2)))
-    if d.defer_reduce:
-      _reduce_on_side(d, 0, ws, (dg, db))
     return dx.view(ctx.shape), _finish(gamma_p, dg, direct), _finish(beta_p, db, direct), None
 
 
@@ -179,13 +175,10 @@ class _LayerNormKeepFn(torch.autograd.Function):
       dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
     d = _desc(x2, ctx.eps)
     d.accumulate = int(direct)
-    d.defer_reduce = int(direct and side_stream_ok(gamma_p, beta_p))
     ws = _ws(d, x2)
     with torch.cuda.device(x2.device):
       _lib.check(_lib.lib().mmt_ln_bwd_add(d, _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(din), _p(dx), _p(dg),
                                            _p(db), _p(ws), ws.numel(), _stream(x2)))
-    if d.defer_reduce:
-      _reduce_on_side(d, 0, ws, (dg, db))
     return dx.view(ctx.shape), _finish(gamma_p, dg, direct), _finish(beta_p, db, direct), None
 
 
@@ -242,14 +235,11 @@ class _ResidualBlockFn(torch.autograd.Function):
       db = torch.empty_like(gamma) if has_ln else None
     d = _desc(x_new, eps, p, seed)
     d.accumulate = int(direct)
-    d.defer_reduce = int(direct and side_stream_ok(bias_p, gamma_p, beta_p))
     ws = _ws(d, x_new)
     with torch.cuda.device(x_new.device):
       _lib.check(_lib.lib().mmt_residual_block_bwd(
           d, _p(dxn), _p(dh2), _p(x_new), _p(gamma), _p(mean), _p(rstd), _p(d_o), _p(dx), _p(dbias),
           _p(dg), _p(db), _p(ws), ws.numel(), _stream(x_new)))
-    if d.defer_reduce:
-      _reduce_on_side(d, 1 if has_ln else 2, ws, (dbias, dg, db) if has_ln else (dbias,))
     return (d_o.view(shape), _finish(bias_p, dbias, direct), dx.view(shape),
             _finish(gamma_p, dg, direct) if has_ln else None,
             _finish(beta_p, db, direct) if has_ln else None, None, None, None)
@@ -285,13 +275,10 @@ class _BiasGeluFn(torch.autograd.Function):
     dbias, direct = _grad_target(ctx.param, bias)
     d = _desc(u2)
     d.accumulate = int(direct)
-    d.defer_reduce = int(direct and side_stream_ok(ctx.param))
     ws = _ws(d, u2)
     with torch.cuda.device(u2.device):
       _lib.check(_lib.lib().mmt_bias_gelu_bwd(d, _p(dy2), _p(u2), _p(bias), _p(du), _p(dbias), _p(ws),
                                               ws.numel(), _stream(u2)))
-    if d.defer_reduce:
-      _reduce_on_side(d, 3, ws, (dbias,))
     return du.view(ctx.shape), _finish(ctx.param, dbias, direct)
 
 
@@ -403,57 +390,7 @@ def wgrad_accumulate_(dw: torch.Tensor, dy: torch.Tensor, x: torch.Tensor, dbias
   return True
 
 
-# ---- weight gradients on a side stream -------------------------------------------------------------
-# The weight-gradient GEMMs are off the critical path of backward (nothing but the optimizer reads dW),
-# while the main stream keeps hitting kernels that cannot fill the chip (global-row / global-key combines,
-# fixed-order reduces: ~100 us per layer at a few hundred waves).  Running every dW GEMM on one side
-# stream lets the hardware fill those holes with GEMM workgroups.  Ordering: the side stream waits for the
-# main stream at the point the GEMM is enqueued (dy and x are final), the main stream waits for the side
-# stream when the backward pass ends (engine callback), and the caching allocator is told about the extra
-# stream (record_stream).  A data-parallel reducer calls `wait_side_streams()` right before it launches a
-# bucket's all-reduce (the collective is ordered against the current stream only).
-# MMT_WGRAD_SIDE_STREAM: 0 (default since the grouped launches) = never, 1 = single-process runs only, 2 = also under
-# a data-parallel reducer.  The side stream was worth 0.4 ms per step while every weight gradient was a launch of
-# its own with a 6- to 24-way split of K; with the block's four products in one launch (queued and launched on the
-# main stream as well, `wgrad_accumulate_deferred_`) the two paths measure the same (15.93 vs 15.98 ms over four
-# same-box pairs), and the single-stream path is the one a data-parallel run takes anyway -- so N = 1 and N > 1 time
-# the same kernels in the same order.  (The 2-rank rehearsal on one GPU over gloo is correct with mode 2 but ~25x
-# slower per step: gloo's CUDA staging path against a second stream.)
-_SIDE_MODE = int(os.environ.get('MMT_WGRAD_SIDE_STREAM', '0'))
-WGRAD_SIDE_STREAM = _SIDE_MODE != 0
-_SIDE = {}
-_side_pending = {}         # device -> id of the backward pass (graph task) whose end-of-backward join is queued
-
-
-def _side_stream(device):
-  s = _SIDE.get(device)
-  if s is None:
-    s = _SIDE[device] = torch.cuda.Stream(device=device)
-    # the GEMMs on this stream co-run with the critical-path kernels: a grid that leaves them some compute
-    # units measured 0.1 ms/step faster than one sized for the whole chip (224 vs 256; 192-240 are flat); the
-    # persistent dgelu GEMM on the main stream likewise (192-224 workgroups: 16.63-16.69 ms/step, 256: 16.73)
-    _lib.lib().mmt_wgrad_set_cu_budget(int(os.environ.get('MMT_WGRAD_CUS', '224')))
-    _lib.lib().mmt_ffn_set_cu_budget(int(os.environ.get('MMT_FFN_CUS', '224')))
-  return s
-
-
-def wait_side_streams():
-  """The current stream waits for everything enqueued on the weight-gradient stream(s) so far."""
-  for device in list(_wg_pending):
-    _flush_wgrad(device)
-  for device in _side_pending:
-    torch.cuda.current_stream(device).wait_stream(_SIDE[device])
-
-
-def _join_side_streams():
-  """Engine callback at the end of backward: the current stream waits for the weight-gradient stream."""
-  for device in list(_wg_pending):
-    _flush_wgrad(device)
-  for device in list(_side_pending):
-    torch.cuda.current_stream(device).wait_stream(_SIDE[device])
-  _side_pending.clear()
-
-
+# ---- weight gradients: grouped launches -----------------------------------------------------------------
 _GRAPH_TASK_ID = getattr(torch._C, '_current_graph_task_id', None)
 
 
@@ -466,15 +403,6 @@ def grouping_is_safe() -> bool:
   id.  Without that symbol every pass would look alike and products left behind by a backward that raised would be
   launched (with dead operands) by the next one: fail closed -- no grouping, every product launched on its own."""
   return _GRAPH_TASK_ID is not None
-
-
-def side_stream_ok(*params) -> bool:
-  """Side stream for these parameters' gradients?  Not under a data-parallel reducer unless forced."""
-  if not WGRAD_SIDE_STREAM:
-    return False
-  if _SIDE_MODE >= 2:
-    return True
-  return not any(getattr(p, '_mmt_grad_ready_hooks', ()) for p in params if p is not None)
 
 
 def _wgrad_groupable(dw, dy, x, dbias) -> bool:
@@ -493,10 +421,11 @@ def _wgrad_groupable(dw, dy, x, dbias) -> bool:
 
 # Weight-gradient products waiting to be launched together (per device): the four Dense layers of an encoder
 # block contract the same rows, and ONE grouped launch (`mmt_wgrad_grouped`) needs a 2-way instead of a 6- to
-# 24-way split of K -- 4x less fp32 slab traffic (~0.2 GB per block).  They are off the critical path of
-# backward (side stream), so waiting for the block's last product costs nothing.
-_WG_GROUP = int(os.environ.get('MMT_WGRAD_GROUP', '4'))
-_wg_pending = {}
+# 24-way split of K -- 4x less fp32 slab traffic (~0.2 GB per block).  Nothing but the optimizer reads dW, so
+# waiting for the block's last product costs nothing.  (Until round 3 a second stream carried these products,
+# MMT_WGRAD_SIDE_STREAM; with the grouped launch the two measured the same -- 15.93 vs 15.98 ms per step over
+# four same-box pairs -- and the form was removed in round 4.)
+_WG_GROUP = 4
 
 
 def _launch_wgrad_group(items, device, stream) -> None:
@@ -518,22 +447,7 @@ def _launch_wgrad_group(items, device, stream) -> None:
     _lib.check(L.mmt_wgrad_grouped(len(items), arr, K, ws.data_ptr(), ws.numel(), stream.cuda_stream))
 
 
-def _flush_wgrad(device) -> None:
-  entry = _wg_pending.pop(device, None)
-  if not entry or not entry[1]:
-    return
-  items = entry[1]
-  side = _side_stream(device)
-  side.wait_stream(torch.cuda.current_stream(device))     # every queued dy / x is final on the main stream
-  with torch.cuda.stream(side):
-    _launch_wgrad_group(items, device, side)
-  for _, dy, x, _ in items:
-    dy.record_stream(side)
-    x.record_stream(side)
-
-
-# The same grouping for parameters that carry gradient-ready hooks (a data-parallel reducer: no side stream by
-# default): the products are queued and launched together on the CURRENT stream, and only then are the
+# The products are queued and launched together on the CURRENT stream, and only then are the
 # parameters reported ready -- the reducer ignores autograd's own post-accumulate notification for a parameter
 # while `_mmt_grad_deferred` is set, so a bucket's all-reduce can never be enqueued ahead of its last product.
 _wg_deferred = {}
@@ -552,12 +466,9 @@ def _flush_wgrad_deferred(device) -> None:
 
 
 def reset_host_queues() -> None:
-  """Forgets every weight-gradient product a backward pass has queued but not launched, and the pending side-stream
-  joins.  For a step that was ABANDONED half-way (a graph capture that raised inside backward, `graphed.py`): its
+  """Forgets every weight-gradient product a backward pass has queued but not launched.  For a step that was ABANDONED half-way (a graph capture that raised inside backward, `graphed.py`): its
   queued products point at activations of a step that never ran; the retry must not launch them."""
-  _wg_pending.clear()
   _wg_deferred.clear()
-  _side_pending.clear()
 
 
 def _flush_all_deferred():
@@ -593,75 +504,12 @@ def wgrad_accumulate_deferred_(dw, dy, x, dbias, notify) -> bool:
   return True
 
 
-def wgrad_accumulate_side_(dw, dy, x, dbias=None) -> bool:
-  """`wgrad_accumulate_` on the side stream (inside a backward pass only).  Products the grouped kernel can take
-  are queued and launched together, `MMT_WGRAD_GROUP` (4) at a time or when backward ends / somebody waits for
-  the side stream; the others go out at once."""
-  device = dw.device
-  if _WG_GROUP > 1 and _wgrad_groupable(dw, dy, x, dbias):
-    gid = _graph_task_id()
-    entry = _wg_pending.get(device)
-    if entry is not None and entry[0] != gid:        # left behind by a backward pass that raised: not ours to launch
-      _wg_pending.pop(device)
-      entry = None
-    if entry is not None and entry[1] and entry[1][0][1].shape[0] != dy.shape[0]:   # another K: cannot share the slices
-      _flush_wgrad(device)
-      entry = None
-    if entry is None:
-      entry = _wg_pending[device] = (gid, [])
-    q = entry[1]
-    q.append((dw, dy, x, dbias))
-    _side_stream(device)
-    _mark_side(device)
-    if len(q) >= _WG_GROUP:
-      _flush_wgrad(device)
-    return True
-  side = _side_stream(device)
-  main = torch.cuda.current_stream(device)
-  side.wait_stream(main)
-  with torch.cuda.stream(side):
-    ok = wgrad_accumulate_(dw, dy, x, dbias)
-  if not ok:
-    return False
-  for t in (dy, x):
-    t.record_stream(side)
-  _mark_side(device)
-  return True
-
-
-def _mark_side(device):
-  # one join per backward pass: keyed by the engine's graph-task id, so a backward that raised before its
-  # callbacks ran (entry left behind) cannot keep a later backward from queueing its own join
-  gid = _graph_task_id()
-  if _side_pending.get(device, None) != gid or gid == -1:
-    _side_pending[device] = gid
-    torch.autograd.Variable._execution_engine.queue_callback(_join_side_streams)
-
-
-def _reduce_on_side(d, kind, ws, outs, *params):
-  """Second half of a *_bwd call made with d.defer_reduce: the fixed-order column-sum reduce (parameter
-  gradients: nothing on the critical path reads them) goes to the side stream."""
-  device = ws.device
-  side = _side_stream(device)
-  side.wait_stream(torch.cuda.current_stream(device))
-  o = list(outs) + [None] * (3 - len(outs))
-  with torch.cuda.stream(side):
-    with torch.cuda.device(device):
-      _lib.check(_lib.lib().mmt_colsum_reduce(d, kind, _p(ws), _p(o[0]), _p(o[1]), _p(o[2]), side.cuda_stream))
-  ws.record_stream(side)
-  for t in outs:
-    if t is not None:
-      t.record_stream(side)
-  _mark_side(device)
-
-
 _WGRAD_WS = {}
 
 
 def _wgrad_ws(device, nbytes):
   """One grow-only scratch buffer per (device, stream) for the split-K slabs: a buffer is only ever used on the stream
-  it was allocated on, so its reuse -- and the release of the one it replaces when it grows -- is stream-ordered even
-  when main-stream and side-stream launches (MMT_WGRAD_SIDE_STREAM) interleave."""
+  it was allocated on, so its reuse -- and the release of the one it replaces when it grows -- is stream-ordered."""
   key = (device, torch.cuda.current_stream(device).cuda_stream)
   buf = _WGRAD_WS.get(key)
   if buf is None or buf.numel() < nbytes:

@@ -9,7 +9,6 @@ torch is the buffer carrier / autograd glue; the attention core runs in the HIP 
 from __future__ import annotations
 
 import math
-import os
 from typing import Callable, Optional
 
 import torch
@@ -86,8 +85,6 @@ def cast_param(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
   return _CastParamFn.apply(param, dtype)
 
 
-_FFN_FUSED = os.environ.get('MMT_FFN_FUSED', '1') != '0'
-_FFN_FWD_FUSED = os.environ.get('MMT_FFN_FWD_FUSED', '0') != '0'
 
 
 def _param_weight(param: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
@@ -115,8 +112,8 @@ def _add_bias_grad(bias, dy2):
 
 def _accumulate_dense_grads(weight, bias, dy2, x2):
   """weight.grad (fp32) += dy2^T @ x2 and bias.grad += dy2.sum(0) for a Dense layer y = x W^T + b, written
-  straight into the master gradients: the hand-written split-K kernel (bias column sums fused, on the
-  weight-gradient side stream when allowed), else library GEMM + accumulate.  Runs the parameters'
+  straight into the master gradients: the hand-written split-K kernel (bias column sums fused, grouped with the
+  block's other products), else library GEMM + accumulate.  Runs the parameters'
   gradient-ready hooks once the writes are enqueued."""
   want_b = bias is not None and bias.requires_grad
   b_done = False
@@ -124,8 +121,7 @@ def _accumulate_dense_grads(weight, bias, dy2, x2):
     if weight.grad is None:
       weight.grad = torch.zeros_like(weight, dtype=torch.float32)
     fuse_b = want_b and bias.grad is not None and bias.grad.dtype == torch.float32 and bias.grad.is_contiguous()
-    side = fused.side_stream_ok(weight, bias)
-    if (not side and weight.is_cuda and weight.grad.dtype == torch.float32
+    if (weight.is_cuda and weight.grad.dtype == torch.float32
         and fused.wgrad_accumulate_deferred_(weight.grad, dy2, x2, bias.grad if fuse_b else None,
                                              (weight, bias) if fuse_b else (weight,))):
       # queued with the block's other weight gradients; the parameters are reported ready at the launch
@@ -133,7 +129,7 @@ def _accumulate_dense_grads(weight, bias, dy2, x2):
         _add_bias_grad(bias, dy2)
         _notify(bias)
       return
-    wgrad = fused.wgrad_accumulate_side_ if side else fused.wgrad_accumulate_
+    wgrad = fused.wgrad_accumulate_
     if weight.grad.dtype == torch.float32 and wgrad(weight.grad, dy2, x2, bias.grad if fuse_b else None):
       b_done = fuse_b
     elif weight.grad.dtype == torch.float32:
@@ -176,8 +172,9 @@ class _LinearFn(torch.autograd.Function):
 
 class _FfnFn(torch.autograd.Function):
   """f = gelu_tanh(x @ W1^T + b1) @ W2^T: the feed-forward pair of one encoder block with the activation inside
-  the GEMM epilogues (`mmt_ffn_gelu_gemm` forward when `MMT_FFN_FWD_FUSED`, `mmt_ffn_dgelu_gemm` backward), so
-  the [B*S, 4H] intermediate is not swept by a separate activation pass.  Parameter gradients as `_LinearFn`."""
+  backward GEMM's epilogue (`mmt_ffn_dgelu_gemm`), so the [B*S, 4H] gradient is not swept by a separate activation
+  pass.  Forward: library GEMM + one bias/GELU pass (the fused forward GEMM, `mmt_ffn_gelu_gemm`, measured slower than
+  that pair and is not used by the model).  Parameter gradients as `_LinearFn`."""
 
   @staticmethod
   def forward(ctx, x, w1, b1, w2):
@@ -185,13 +182,8 @@ class _FfnFn(torch.autograd.Function):
     x2 = x.reshape(-1, x.shape[-1])
     if not x2.is_contiguous():
       x2 = x2.contiguous()
-    ug = fused.ffn_gelu_gemm(x2, w1s, b1.detach()) if _FFN_FWD_FUSED else None
-    ctx.u_has_bias = ug is not None
-    if ug is None:                       # library GEMM + activation pass; u is kept WITHOUT the bias
-      u = F.linear(x2, w1s)
-      g = fused.bias_gelu_forward_(u, b1.detach())
-    else:
-      u, g = ug
+    u = F.linear(x2, w1s)                # library GEMM + activation pass; u is kept WITHOUT the bias
+    g = fused.bias_gelu_forward_(u, b1.detach())
     ctx.save_for_backward(x2, u, g, w1s, w2s)
     ctx.params = (w1, b1, w2)
     ctx.shape = x.shape
@@ -205,7 +197,7 @@ class _FfnFn(torch.autograd.Function):
     if not df2.is_contiguous():
       df2 = df2.contiguous()
     _accumulate_dense_grads(w2, None, df2, g)
-    du = fused.ffn_dgelu_gemm(df2, w2s, u, None if ctx.u_has_bias else b1.detach())
+    du = fused.ffn_dgelu_gemm(df2, w2s, u, b1.detach())
     if du is None:
       raise RuntimeError('mmt_ffn_dgelu_gemm refused a shape _ffn_ok admitted')
     _accumulate_dense_grads(w1, b1, du, x2)
@@ -227,7 +219,6 @@ def _linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor])
   return F.linear(x, cast_param(weight, x.dtype), None if bias is None else cast_param(bias, x.dtype))
 
 
-_TIED_DGRAD_SPLIT = os.environ.get('MMT_TIED_DGRAD_SPLIT', '1') != '0'
 
 
 class _TiedLogitsFn(torch.autograd.Function):
@@ -252,7 +243,7 @@ class _TiedLogitsFn(torch.autograd.Function):
     dx = None
     if ctx.needs_input_grad[0]:
       M, V = dy.shape
-      if (_TIED_DGRAD_SPLIT and dy.is_cuda and dy.dtype == torch.bfloat16 and dy.is_contiguous() and w.is_contiguous()
+      if (dy.is_cuda and dy.dtype == torch.bfloat16 and dy.is_contiguous() and w.is_contiguous()
           and V % 3 == 0 and V >= 8192 and M * w.shape[1] <= (1 << 21)):
         # [M, V] . [V, H] with a long V and a small M x H has 12-64 output tiles for 256 CUs and no split-K solution in
         # the tuned library set (149 us at 0.32 PFLOP/s at M = 1024): three K slices as one batched product (103 us,
@@ -436,7 +427,7 @@ class RelativeTransformerLayers(nn.Module):
       ln2 = layer.ffn_layer_norm
       x, h2 = fused.residual_block(o, layer.attention.output_bias, x, ln2.weight, ln2.bias, ln2.eps,
                                    p, fused.next_seed(dropout_seed) if p else 0)
-      if _FFN_FUSED and _ffn_ok(h2, layer.intermediate_weight, layer.intermediate_bias, layer.ffn_output_weight):
+      if _ffn_ok(h2, layer.intermediate_weight, layer.intermediate_bias, layer.ffn_output_weight):
         f = _FfnFn.apply(h2, layer.intermediate_weight, layer.intermediate_bias, layer.ffn_output_weight)
       else:
         u = _linear(h2, layer.intermediate_weight, None)
