@@ -350,7 +350,6 @@ template <int REL, bool DROP>        // REL: 0 no relative term, 1 = 1-D ids (pe
 __global__ __launch_bounds__(512, 4) void attn_fwd_win_bf16_kernel(const FwdParams p) {
   using T = __bf16;
   constexpr bool HAS_REL = REL != 0;
-  constexpr int Rp = 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

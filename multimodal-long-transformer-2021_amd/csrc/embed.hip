@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const EmbedParams p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float w = (v[j][i] - mean) * rstd * g[i] + bt[i];
-        if (p.thresh16) w = drop_bits16(sd.lo, sd.hi, (uint64_t)(off + i)) >= p.thresh16 ? w * p.inv_keep : 0.f;
+        if (p.thresh16) w = layer_drop_bits16(layer_drop_row(sd.lo, sd.hi, row), (uint32_t)(c * 8 + i)) >= p.thresh16 ? w * p.inv_keep : 0.f;
         y[i] = w;
       }
       if (sg_ok) {
@@ -194,12 +194,11 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const EmbedParams p) {
         for (int j = 0; j < NCH; ++j) {
           const int c = lane + 64 * j;
           if (c >= nch) continue;
-          const long off = (long)row * p.H + c * 8;
           if (to_patch) Chunk<T>::store(reinterpret_cast<T*>(p.dpatch) + ((long)b * p.n_patch + pj) * p.H + c * 8, t[u][j]);
 #pragma unroll
           for (int i = 0; i < 8; ++i) {
             float v = t[u][j][i];
-            if (p.thresh16) v = drop_bits16(sd.lo, sd.hi, (uint64_t)(off + i)) >= p.thresh16 ? v * p.inv_keep : 0.f;
+            if (p.thresh16) v = layer_drop_bits16(layer_drop_row(sd.lo, sd.hi, (long)row), (uint32_t)(c * 8 + i)) >= p.thresh16 ? v * p.inv_keep : 0.f;
             tsum[j][i] += v;
           }
         }

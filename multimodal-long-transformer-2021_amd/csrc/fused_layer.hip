@@ -41,36 +41,68 @@ struct LayerParams {
 // =============================================================================================
 template <typename T, int W, int NCH, bool RESID, bool HAS_LN>
 __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const LayerParams p) {
+  // Persistent: a wave walks rows blockIdx * 4 + wave, + 4 gridDim, ... with the NEXT row's inputs requested before the
+  // current row's reductions (raw registers, converted when their turn comes) and bias / gamma / beta loaded once per wave
+  // (round 4; one row per wave and nine parameter loads per row until then: 23-26 us for the 101 MB of a residual block).
   const SeedPair sd = effective_seed(p.seed_lo, p.seed_hi, p.epoch);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = p.H / W;
   const float invH = 1.f / (float)p.H;
-  for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
-    float v[NCH][W];
+  float bs[NCH][W], g[NCH][W], bt[NCH][W];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c = lane + 64 * j;
+#pragma unroll
+    for (int i = 0; i < W; ++i) { bs[j][i] = 0.f; g[j][i] = 0.f; bt[j][i] = 0.f; }
+    if (c < nch) {
+      if (RESID) load_param_w<W>(p.p0 + c * W, bs[j]);
+      if (HAS_LN) { load_param_w<W>(p.p1 + c * W, g[j]); load_param_w<W>(p.p2 + c * W, bt[j]); }
+    }
+  }
+  const long stride = (long)gridDim.x * 4;
+  long row = (long)blockIdx.x * 4 + wave;
+  RawW<T, W> ra[NCH], rb[NCH];             // o, x as loaded
+  auto request = [&](long r) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int c = lane + 64 * j;
+      ra[j].zero(); rb[j].zero();
       if (c < nch) {
-        const long off = row * p.H + c * W;
-        if (RESID) {
-          float o[W], x[W], bs[W];
-          ChunkW<T, W>::load(reinterpret_cast<const T*>(p.a) + off, o);
-          ChunkW<T, W>::load(reinterpret_cast<const T*>(p.b) + off, x);
-          load_param_w<W>(p.p0 + c * W, bs);
+        const long off = r * p.H + c * W;
+        if (RESID) ra[j].load(reinterpret_cast<const T*>(p.a) + off);
+        rb[j].load(reinterpret_cast<const T*>(p.b) + off);
+      }
+    }
+  };
+  if (row < p.rows) request(row);
+  for (; row < p.rows; row += stride) {
+    float v[NCH][W];
+    const uint32_t drow = layer_drop_row(sd.lo, sd.hi, row);
 #pragma unroll
-          for (int i = 0; i < W; ++i) {
-            float t = o[i] + bs[i];
-            if (p.thresh16) t = drop_bits16(sd.lo, sd.hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
-            v[j][i] = x[i] + t;
-            if (sizeof(T) == 2) v[j][i] = (float)(__bf16)v[j][i];      // LayerNorm sees the stored (rounded) x_new
-          }
-          ChunkW<T, W>::store(reinterpret_cast<T*>(p.o0) + off, v[j]);
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+#pragma unroll
+      for (int i = 0; i < W; ++i) {
+        if (RESID) {
+          float t = ra[j].get(i) + bs[j][i];
+          if (p.thresh16) t = layer_drop_bits16(drow, (uint32_t)(c * W + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
+          v[j][i] = rb[j].get(i) + t;
+          if (sizeof(T) == 2) v[j][i] = (float)(__bf16)v[j][i];      // LayerNorm sees the stored (rounded) x_new
         } else {
-          ChunkW<T, W>::load(reinterpret_cast<const T*>(p.b) + off, v[j]);
+          v[j][i] = rb[j].get(i);
         }
-      } else {
+      }
+      if (c >= nch) {
 #pragma unroll
         for (int i = 0; i < W; ++i) v[j][i] = 0.f;
+      }
+    }
+    if (row + stride < p.rows) request(row + stride);          // in flight under this row's reductions and stores
+    if (RESID) {
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nch) ChunkW<T, W>::store(reinterpret_cast<T*>(p.o0) + row * p.H + c * W, v[j]);
       }
     }
     if (HAS_LN) {
@@ -92,11 +124,9 @@ __global__ __launch_bounds__(256) void resid_ln_fwd_kernel(const LayerParams p) 
       for (int j = 0; j < NCH; ++j) {
         const int c = lane + 64 * j;
         if (c < nch) {
-          float g[W], bt[W], y[W];
-          load_param_w<W>(p.p1 + c * W, g);
-          load_param_w<W>(p.p2 + c * W, bt);
+          float y[W];
 #pragma unroll
-          for (int i = 0; i < W; ++i) y[i] = (v[j][i] - mean) * rstd * g[i] + bt[i];
+          for (int i = 0; i < W; ++i) y[i] = (v[j][i] - mean) * rstd * g[j][i] + bt[j][i];
           ChunkW<T, W>::store(reinterpret_cast<T*>(p.o1) + row * p.H + c * W, y);
         }
       }
@@ -128,6 +158,7 @@ __global__ __launch_bounds__(256, (W * NCH <= 12 ? 4 : 1)) void resid_ln_bwd_ker
   // two wave reductions and are converted twice.
   for (long row = (long)blockIdx.x * 4 + wave; row < p.rows; row += (long)gridDim.x * 4) {
     RawW<T, W> ra[NCH], rb[NCH], rc[NCH];      // dx_in, dh, x_new
+    const uint32_t drow = layer_drop_row(sd.lo, sd.hi, row);
     float mean = 0.f, rstd = 0.f;
     if (HAS_LN) { mean = p.mean[row]; rstd = p.rstd[row]; }
 #pragma unroll
@@ -179,7 +210,7 @@ __global__ __launch_bounds__(256, (W * NCH <= 12 ? 4 : 1)) void resid_ln_bwd_ker
 #pragma unroll
           for (int i = 0; i < W; ++i) {
             float t = dx[i];
-            if (p.thresh16) t = drop_bits16(sd.lo, sd.hi, (uint64_t)(off + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
+            if (p.thresh16) t = layer_drop_bits16(drow, (uint32_t)(ch * W + i)) >= p.thresh16 ? t * p.inv_keep : 0.f;
             d_o[i] = t;
             acc_b[j][i] += t;
           }
@@ -504,9 +535,9 @@ int check_rows(const mmt_rows_desc* d, int max_h) {
 }
 
 // forward kernels have no per-block partial slab: one row per wave up to 4096 blocks
-int row_blocks_fwd(const mmt_rows_desc* d) {
+int row_blocks_fwd(const mmt_rows_desc* d) {      // persistent forward kernels: at most the waves an MI355X holds at once
   const long need = (d->rows + 3) / 4;
-  return (int)(need < 4096 ? need : 4096);
+  return (int)(need < 1024 ? need : 1024);
 }
 
 int row_blocks(const mmt_rows_desc* d) {

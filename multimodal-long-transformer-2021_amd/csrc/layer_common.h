@@ -88,17 +88,35 @@ template <int W> __device__ __forceinline__ void load_param_w(const float* p, fl
 
 __device__ __forceinline__ void load_param(const float* p, float (&v)[8]) { Chunk<float>::load(p, v); }
 
+// Sum over the 64 lanes, the same value in every lane.  Butterfly order (lane ^ 1, ^ 2, ^ 4, ^ 8, ^ 16, ^ 32) as DPP adds
+// and gfx950's lane-row swaps: no LDS round trip (six ds_bpermute, ~100 cycles each in a dependent chain, until round 4).
 __device__ __forceinline__ float wave_sum(float x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-  return x;
+#define MMT_DPP_ADD(ctrl) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true))
+  MMT_DPP_ADD(0xB1);     // quad_perm [1,0,3,2]
+  MMT_DPP_ADD(0x4E);     // quad_perm [2,3,0,1]
+  MMT_DPP_ADD(0x141);    // row_half_mirror (quads are uniform by now: lane ^ 4)
+  MMT_DPP_ADD(0x140);    // row_mirror (groups of 8 are uniform: lane ^ 8)
+#undef MMT_DPP_ADD
+  // (inline asm with two distinct registers: given the same value for both operands, hipcc's builtin folds the two
+  //  results into one -- `v_add_f32 v, v, v` after the swap)
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));       // rows (0,1) and (2,3) exchanged
+  x = a + b;
+  a = x; b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));       // halves exchanged
+  return a + b;
 }
 
-// 16 random bits per element, one 32-bit mix per element pair (restated in oracle/layer_ops.py).
-__host__ __device__ __forceinline__ uint32_t drop_bits16(uint32_t seed_lo, uint32_t seed_hi, uint64_t idx) {
-  const uint64_t pair = idx >> 1;
-  const uint32_t hsh = mix32((uint32_t)pair * 0x9E3779B9u + mix32((uint32_t)(pair >> 32) ^ seed_hi) + seed_lo);
-  return (idx & 1) ? (hsh >> 16) : (hsh & 0xFFFFu);
+// Dropout of the row-wise kernels: 16 random bits per element from the attention kernels' hash (mmt_common.h:
+// drop_row_base / drop_pair_finish) on (row, column) -- per row one scalar mix, per element PAIR one xor, two
+// shift-xors and one 24-bit multiply (all full rate); the pair terms (column >> 1) * kDropPairMul do not depend on
+// the row.  (Until round 4: two 32-bit mixes of the flat 64-bit element index per pair -- 62 quarter-rate
+// multiplies per row and lane in the residual kernel.)  Restated in oracle/layer_ops.py.
+__host__ __device__ __forceinline__ uint32_t layer_drop_row(uint32_t seed_lo, uint32_t seed_hi, long row) {
+  return drop_row_base(seed_lo, seed_hi, (uint32_t)((uint64_t)row >> 32), (uint32_t)row);
+}
+__host__ __device__ __forceinline__ uint32_t layer_drop_bits16(uint32_t row_base, uint32_t col) {
+  return drop_bits16(row_base, col);
 }
 
 // GELU, tanh approximation (mmt_encoder.py:53-54): returns gelu(z), dz = gelu'(z).

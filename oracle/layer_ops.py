@@ -6,7 +6,7 @@ Follows SURVEY.md App. A.3 (etcmodel ResidualBlock / DenseLayers in pre-activati
 package is un-vendored, so this part of the float path is PARITY UNPINNED like
 oracle/attention.py) and `src/modeling/models/mmt_encoder.py:53-54` (approximate GELU).
 The dropout keep mask restates the counter hash of the product kernels bit for bit
-(`csrc/fused_layer.hip: drop_bits16`, `csrc/mmt_common.h: mix32`) so masks can be compared
+(`csrc/layer_common.h: layer_drop_bits16`, `csrc/mmt_common.h: mix32, drop_row_base, drop_pair_finish`) so masks can be compared
 exactly; TF's own RNG stream is not reproducible and is not part of parity.
 """
 from __future__ import annotations
@@ -25,15 +25,19 @@ def _mix32(x):
 
 
 def dropout_keep_mask(rows: int, H: int, p: float, seed: int) -> np.ndarray:
-  """keep[row, col] of the fused kernels: 16 bits per element, one mix per element pair."""
+  """keep[row, col] of the fused row-wise kernels (csrc/layer_common.h: layer_drop_row / layer_drop_bits16): the
+  attention kernels' hash (csrc/mmt_common.h: drop_row_base, drop_pair_finish) on (row, column) -- 16 bits per
+  element, one mix per row and one finisher (xor, fold, 24-bit multiply, fold) per column pair."""
   thresh = min(max(int(p * 65536.0 + 0.5), 1), 65535)
-  idx = np.arange(rows * H, dtype=np.uint64)
-  pair = idx >> np.uint64(1)
   seed_lo, seed_hi = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
-  inner = _mix32((pair >> np.uint64(32)) ^ seed_hi)
-  h = _mix32(((pair & _M32) * np.uint64(0x9E3779B9) + inner + seed_lo) & _M32)
-  bits = np.where(idx & np.uint64(1), h >> np.uint64(16), h & np.uint64(0xFFFF))
-  keep = (bits >= np.uint64(thresh)).reshape(rows, H)
+  row = np.arange(rows, dtype=np.uint64).reshape(rows, 1)
+  col = np.arange(H, dtype=np.uint64).reshape(1, H)
+  row_base = (_mix32(seed_lo ^ (((row >> np.uint64(32)) * np.uint64(0x9E3779B9)) & _M32)) + seed_hi
+              + (row & _M32) * np.uint64(0x85EBCA6B)) & _M32
+  x = row_base ^ (((col >> np.uint64(1)) * np.uint64(0xC2B2AE35)) & _M32)
+  x ^= x >> np.uint64(16); x = ((x & np.uint64(0xFFFFFF)) * np.uint64(0xEB352D)) & _M32; x ^= x >> np.uint64(15)
+  bits = np.where((col & np.uint64(1)) == 1, x >> np.uint64(16), x & np.uint64(0xFFFF))
+  keep = bits >= np.uint64(thresh)
   return keep, 65536.0 / (65536.0 - thresh)
 
 

@@ -150,3 +150,21 @@ def test_dropout_keep_mask_statistics():
       assert c(m[:, :, :-64], m[:, :, 64:]) < 2.5e-3 and c(m[:, :-32], m[:, 32:]) < 2.5e-3
       sd = np.sqrt(p * (1 - p) / 768)
       assert abs(m.mean(2).std() - sd) < 0.15 * sd and abs(m.mean(1).std() - sd) < 0.15 * sd
+
+
+def test_layer_dropout_keep_mask_statistics():
+  """The row-wise kernels' dropout mask (round 4: the same hash on (row, column): csrc/layer_common.h, restated in
+  oracle.layer_ops.dropout_keep_mask) at the residual block's shape: keep rate, binomial row / column spread, neighbour
+  correlations along the row, down the column and on the diagonals."""
+  from oracle import layer_ops as lo
+  for p in (0.1, 0.5):
+    for seed in (1234, 0x9ABCDEF012345678, (3 * 0x9E3779B97F4A7C15 + 11) & ((1 << 64) - 1)):
+      keep, inv_keep = lo.dropout_keep_mask(4096, 768, p, seed)
+      m = keep.astype(np.float64)
+      assert abs(m.mean() - 1.0 / inv_keep) < 6e-4 and abs(1.0 / inv_keep - (1 - p)) < 1e-4
+      c = lambda a, b: abs(float(np.corrcoef(a.ravel(), b.ravel())[0, 1]))
+      for a, b in ((m[:, :-1], m[:, 1:]), (m[:, :-2], m[:, 2:]), (m[:-1], m[1:]), (m[:-2], m[2:]), (m[:-4], m[4:]),
+                   (m[:-1, :-1], m[1:, 1:]), (m[:-1, 1:], m[1:, :-1]), (m[:, :-128], m[:, 128:])):
+        assert c(a, b) < 2.5e-3
+      assert abs(m.mean(1).std() - np.sqrt(p * (1 - p) / 768)) < 0.1 * np.sqrt(p * (1 - p) / 768)
+      assert abs(m.mean(0).std() - np.sqrt(p * (1 - p) / 4096)) < 0.1 * np.sqrt(p * (1 - p) / 4096)
