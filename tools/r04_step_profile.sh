@@ -6,6 +6,7 @@ D=gpurun_out/$TAG
 rm -rf $D; mkdir -p $D
 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline > $D/bench.json 2> $D/bench.err || { tail -5 $D/bench.err; exit 1; }
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/ks -o s -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --mode train_step > $D/profiled_bench.json 2>/dev/null || exit 2
+python3 tools/step_trace.py $D/ks $D/last_step.csv > $D/last_step.txt; cat $D/last_step.txt | head -8
 find $D -name '*_kernel_trace.csv' -delete; find $D -name '*agent_info.csv' -delete
 python3 - <<PY
 import json,csv
