@@ -96,7 +96,7 @@ typedef struct mmt_mask_desc {
 /* One attention call: q,k,v,out are [B,S,N,D] views with element strides (D contiguous). */
 typedef struct mmt_attn_desc {
   int32_t B, S, N, D;   /* D must be 64                                               */
-  int32_t R;            /* rows of relative_emb_table (relative_vocab_size); 0 = none */
+  int32_t R;            /* rows of relative_emb_table (relative_vocab_size); 0 = none; at most 128 (above 64: the general kernels) */
   int32_t dtype;        /* MMT_F32 | MMT_BF16 : element type of q,k,v,out,rel tables  */
   int64_t q_stride[3];  /* element strides of (b, s, n) for q                         */
   int64_t k_stride[3];

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void attn_bwd_dq_ker
 // Global rows: sum the chunk partials, add dRel.E, write dQ and the row's dRel (for dE/dbias).
 template <typename T>
 __global__ __launch_bounds__(64) void attn_bwd_dq_combine_kernel(const BwdParams p) {
-  __shared__ float dr_s[64];
+  __shared__ float dr_s[128];
   dq_combine_row<T>(p, blockIdx.y, blockIdx.x, threadIdx.x, dr_s, [] { __syncthreads(); });
 }
 
@@ -648,7 +648,8 @@ static hipError_t launch_bwd_one(const BwdParams& p_in, hipStream_t st) {
 template <typename T, int MODE, bool GEN>
 static hipError_t launch_bwd_rp(const BwdParams& p, hipStream_t st) {
   if (p.Rp == 32) return launch_bwd_one<T, MODE, 32, GEN>(p, st);
-  return launch_bwd_one<T, MODE, 64, GEN>(p, st);
+  if (p.Rp == 64) return launch_bwd_one<T, MODE, 64, GEN>(p, st);
+  return launch_bwd_one<T, MODE, 128, GEN>(p, st);
 }
 
 template <typename T>
@@ -679,7 +680,7 @@ hipError_t launch_drel_reduce(const BwdParams& p, bool bf16, hipStream_t st) {
 }
 
 hipError_t launch_attn_bwd(const BwdParams& p, int mode, bool bf16, hipStream_t st) {
-  if (mode == kBand && bf16 && (p.pat.id_mode == 0 || p.perm_1d || p.lean2d)) return launch_attn_bwd_band_bf16(p, st);
+  if (mode == kBand && bf16 && (p.pat.id_mode == 0 || (p.perm_1d && p.Rp <= 64) || p.lean2d)) return launch_attn_bwd_band_bf16(p, st);
   return bf16 ? launch_bwd_t<__bf16>(p, mode, st) : launch_bwd_t<float>(p, mode, st);
 }
 

@@ -18,23 +18,31 @@ __device__ __forceinline__ void dq_combine_row(const BwdParams& p, int bn, int r
   const int b = bn / p.N, n = bn - b * p.N;
   const int q = p.pat.g0 + row;
   const long slot0 = ((long)bn * p.n_gblk + gblk) * p.n_chunks;
-  float acc = 0.f, dr = 0.f;
+  // thread d sums output column d of dQ and table columns d (and 64 + d when the table is 128 wide: dr_s then holds
+  // 128 floats -- only the general kernels' combine launch runs at that width)
+  float acc = 0.f, dr = 0.f, dr2 = 0.f;
+  const bool wide = p.Rp > 64;
   const float* pq = p.part_dq + slot0 * (32 * 64) + rr * 64 + d;
   const float* pt = p.part_dtab + slot0 * (32 * p.Rp) + rr * p.Rp + (d < p.Rp ? d : 0);
   const long tq = 32 * 64, tt = 32 * p.Rp;
   int c = 0;
   for (; c + 4 <= p.n_chunks; c += 4) {          // four chunks' loads in flight, summed in chunk order
-    float a[4], t[4];
+    float a[4], t[4], t2[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { a[u] = pq[(c + u) * tq]; t[u] = pt[(c + u) * tt]; }
+    for (int u = 0; u < 4; ++u) { a[u] = pq[(c + u) * tq]; t[u] = pt[(c + u) * tt]; t2[u] = wide ? pt[(c + u) * tt + 64] : 0.f; }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { acc += a[u]; dr += t[u]; }
+    for (int u = 0; u < 4; ++u) { acc += a[u]; dr += t[u]; dr2 += t2[u]; }
   }
-  for (; c < p.n_chunks; ++c) { acc += pq[c * tq]; dr += pt[c * tt]; }
+  for (; c < p.n_chunks; ++c) { acc += pq[c * tq]; dr += pt[c * tt]; if (wide) dr2 += pt[c * tt + 64]; }
   if (d >= p.Rp) dr = 0.f;
   if (d >= p.R) dr = 0.f;
+  if (64 + d >= p.R) dr2 = 0.f;
   dr_s[d] = dr;
   if (d < p.Rp) p.drel[((long)bn * p.pat.ng + row) * p.Rp + d] = dr;
+  if (wide) {
+    dr_s[64 + d] = dr2;
+    p.drel[((long)bn * p.pat.ng + row) * p.Rp + 64 + d] = dr2;
+  }
   sync();
   const T* E = reinterpret_cast<const T*>(p.emb) + (long)n * 64;
   for (int id = 0; id < p.R; ++id) acc = fmaf(dr_s[id], (float)E[(long)id * p.N * 64 + d], acc);

@@ -339,6 +339,8 @@ __global__ __launch_bounds__(64) void attn_rows_combine_kernel(const FwdParams p
 template <typename T, int MODE, int Rp, bool GEN>
 static hipError_t launch_one(const FwdParams& p, dim3 grid, hipStream_t st) {
   const int lds = 4 * WaveLds<T, Rp>::kBytes;
+  if (lds > 64 * 1024)               // (the 128-wide table: relative vocabularies of 65..128 ids)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<T, MODE, Rp, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   hipLaunchKernelGGL((attn_fwd_kernel<T, MODE, Rp, GEN>), grid, dim3(256), lds, st, p);
   return hipGetLastError();
 }
@@ -346,7 +348,8 @@ static hipError_t launch_one(const FwdParams& p, dim3 grid, hipStream_t st) {
 template <typename T, int MODE, bool GEN>
 static hipError_t launch_rp(const FwdParams& p, dim3 grid, hipStream_t st) {
   if (p.R <= 32) return launch_one<T, MODE, 32, GEN>(p, grid, st);
-  return launch_one<T, MODE, 64, GEN>(p, grid, st);
+  if (p.R <= 64) return launch_one<T, MODE, 64, GEN>(p, grid, st);
+  return launch_one<T, MODE, 128, GEN>(p, grid, st);
 }
 
 template <typename T>

@@ -59,7 +59,7 @@ int check_desc(const mmt_attn_desc* d) {
   if (!d) return fail(MMT_E_INVALID, "desc is NULL");
   if (d->B <= 0 || d->S <= 0 || d->N <= 0) return fail(MMT_E_INVALID, "B,S,N must be positive");
   if (d->D != 64) return fail(MMT_E_UNSUPPORTED, "D=%d: only head size 64 is built", d->D);
-  if (d->R < 0 || d->R > 64) return fail(MMT_E_UNSUPPORTED, "R=%d: relative vocab must be in [0,64]", d->R);
+  if (d->R < 0 || d->R > 128) return fail(MMT_E_UNSUPPORTED, "R=%d: relative vocab must be in [0,128]", d->R);
   if (d->dtype != MMT_F32 && d->dtype != MMT_BF16) return fail(MMT_E_INVALID, "bad dtype %d", d->dtype);
   const int64_t* st[4] = {d->q_stride, d->k_stride, d->v_stride, d->o_stride};
   const int align = d->dtype == MMT_BF16 ? 8 : 4;  // 16-byte row loads
@@ -110,7 +110,7 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
     pl.fwd_ws = std::max(pl.fwd_ws, mmt::fwd_pwin_workspace_bytes(d->B, d->N, d->S, 2 * 256));
   }
   // backward: delta, dRel, global-row / global-key partials, dE partials (floats)
-  const size_t bn = (size_t)d->B * d->N, Rp = d->R <= 32 ? 32 : 64;
+  const size_t bn = (size_t)d->B * d->N, Rp = d->R <= 32 ? 32 : (d->R <= 64 ? 64 : 128);
   pl.n_split = (int)std::min<size_t>(256, ((size_t)d->B * d->S + 255) / 256);
   pl.off_delta = 0;
   pl.off_relfar = pl.off_delta + bn * d->S;
@@ -223,7 +223,7 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     p.part_ml = p.part_o + (size_t)desc->B * desc->N * pl.n_rowblk * pl.n_chunks * (32 * 64);
   }
   p.lean_rp = lean2d_width(p.pat, desc->R, dense);
-  const bool lean = bf16 && (p.pat.id_mode == 0 || p.perm_1d || p.lean_rp);   // attn_fwd_band.hip
+  const bool lean = bf16 && (p.pat.id_mode == 0 || (p.perm_1d && desc->R <= 64) || p.lean_rp);   // attn_fwd_band.hip (tables up to 64 wide)
   p.part_scale = (lean && p.drop_thresh) ? p.inv_keep : 1.f;
   // window kernel (attn_fwd_win.hip): K / V staged once per workgroup, global keys as a peeled quarter-tile step,
   // rows of up to 16 global tokens by flipped-orientation workgroups of the same launch (no workspace, no combine
@@ -323,7 +323,7 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   p.q = q; p.k = k; p.v = v; p.emb = rel_emb; p.bias = rel_bias; p.out = out; p.dout = dout; p.lse = lse;
   p.att_mask = att_mask; p.rel_ids = rel_ids; p.valid_len = f.valid_len;
   p.dq = dq; p.dk = dk; p.dv = dv; p.drel_emb = drel_emb; p.drel_bias = rel_bias ? drel_bias : nullptr;
-  p.B = f.B; p.S = f.S; p.N = f.N; p.R = f.R; p.Rp = desc->R <= 32 ? 32 : 64;
+  p.B = f.B; p.S = f.S; p.N = f.N; p.R = f.R; p.Rp = desc->R <= 32 ? 32 : (desc->R <= 64 ? 64 : 128);
   for (int i = 0; i < 3; ++i) { p.qs[i] = f.qs[i]; p.ks[i] = f.ks[i]; p.vs[i] = f.vs[i]; p.os[i] = f.os[i]; }
   p.sscale = f.sscale; p.tscale = f.tscale; p.mask_add = f.mask_add;
   p.gscale = desc->scale;
@@ -363,7 +363,7 @@ int mmt_attn_bwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   p.dkv_slots = p.n_chunks;
   {   // P / dS hand-over: the dK/dV pass reads what the dQ pass computed (needs the peeled kind of global tokens, if any)
     const bool on = !(desc->tuning & MMT_TUNE_BWD_NO_HANDOVER);
-    const bool lean = desc->dtype == MMT_BF16 && !dense && (p.pat.id_mode == 0 || p.perm_1d || p.lean2d);
+    const bool lean = desc->dtype == MMT_BF16 && !dense && (p.pat.id_mode == 0 || (p.perm_1d && p.Rp <= 64) || p.lean2d);
     if (on && lean && pl.ho_slots > 0 && (p.pat.ng == 0 || !pl.split_rows || (p.peel_gkeys & 1))) {
       p.ho = reinterpret_cast<unsigned char*>(ws + pl.off_ho);
       p.ho_slots = pl.ho_slots;

@@ -121,6 +121,9 @@ def test_argument_errors_without_gpu(lib):
   assert L.mmt_workspace_bytes(d) == 0
   assert b'head size 64' in L.mmt_last_error()
   d.D = 64
+  d.R = 129                                                # tables are built up to 128 ids wide
+  assert L.mmt_workspace_bytes(d) == 0 and b'[0,128]' in L.mmt_last_error()
+  d.R = 0
   d.dtype = lib.MMT_BF16
   for arr in (d.q_stride, d.k_stride, d.v_stride, d.o_stride):
     arr[:] = (64 * 64, 64, 64)

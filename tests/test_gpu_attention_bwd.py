@@ -72,6 +72,8 @@ DTYPES = [torch.float32, torch.bfloat16]
     dict(B=1, S=96, N=2, R=49, id_mode=2, m=12, P=6, r=2),
     dict(B=1, S=96, N=2, R=9, scale_before_add=True),
     dict(B=1, S=96, N=2, R=9, use_bias=False),
+    dict(B=1, S=128, N=2, R=100, m=40),                          # relative vocabulary above 64: the 128-wide table
+    dict(B=1, S=112, N=2, R=121, id_mode=2, m=12, P=8, r=4),     # 2-D ids with a 9 x 9 core window
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'R', 'id_mode')))
 def test_dense_operator_backward(cfg, dtype):
   run_bwd(dtype=dtype, dense=True, **cfg)
@@ -100,6 +102,8 @@ def test_dense_operator_backward(cfg, dtype):
     dict(B=1, S=96, N=1, R=1, radius=16, m=0),                             # a single relative id (m = 0)
     # BASELINE config 2 shape: S=1024 = 2 + 28^2 + 238 text, radius 64, 8 globals [786,794) (fp32 there)
     dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),
+    dict(B=1, S=320, N=2, R=100, radius=64, g0=250, ng=8, m=40),           # relative vocabulary above 64 (general kernels, 128-wide table)
+    dict(B=1, S=210, N=2, R=128, radius=24, g0=150, ng=5, id_mode=2, m=12, P=10, r=4),
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'id_mode')))
 def test_structured_pattern_backward(cfg, dtype):
   run_bwd(dtype=dtype, dense=False, **cfg)

@@ -72,6 +72,8 @@ DTYPES = [torch.float32, torch.bfloat16]
     dict(B=1, S=64, N=2, R=20, id_mode=2, m=3, P=3, r=1, valid=[50]),
     dict(B=1, S=96, N=2, R=9, scale_before_add=True),
     dict(B=1, S=96, N=2, R=9, use_bias=False),
+    dict(B=1, S=128, N=2, R=100, m=40),                          # relative vocabulary above 64: the 128-wide table
+    dict(B=1, S=112, N=2, R=121, id_mode=2, m=12, P=8, r=4),     # 2-D ids with a 9 x 9 core window
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'R', 'id_mode')))
 def test_dense_operator(cfg, dtype):
   """K3: the literal reference operator (dense int32 att_mask / relative_att_ids)."""
@@ -99,6 +101,8 @@ def test_dense_operator(cfg, dtype):
     dict(B=1, S=20, N=2, R=9, radius=4, g0=0, ng=1),                       # shorter than one 32-row tile
     dict(B=1, S=96, N=1, R=1, radius=16, m=0),                             # a single relative id (m = 0)
     dict(B=1, S=1024, N=2, R=32, radius=64, g0=786, ng=8, m=12),           # BASELINE config 2 shape (N cut)
+    dict(B=1, S=320, N=2, R=100, radius=64, g0=250, ng=8, m=40),           # relative vocabulary above 64 (general kernels, 128-wide table)
+    dict(B=1, S=210, N=2, R=128, radius=24, g0=150, ng=5, id_mode=2, m=12, P=10, r=4),
 ], ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items() if k in ('S', 'radius', 'ng', 'id_mode')))
 def test_structured_pattern(cfg, dtype):
   """K1+K2: in-kernel mask/id generation vs the dense oracle fed the materialised pattern."""
