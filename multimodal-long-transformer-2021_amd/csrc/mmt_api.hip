@@ -276,9 +276,11 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   // The window kernel's flipped-rows workgroups walk ALL key tiles of their plane (8 waves x S / 256 tiles each): at
   // S = 8192 one lives longer than the band workgroups of the whole launch take (config 5, g = 8: window 52.7 us,
   // per-wave 47.1 us per call; at S = 4096: 46.0 against 48.5), so beyond 4096 positions the per-wave kernel keeps
-  // the call unless the window kernel is forced.
+  // the call unless the window kernel is forced.  Without global tokens the window kernel has nothing to win -- what it
+  // made cheaper is the global tokens -- and the per-wave kernel, whose waves never meet at a barrier, is 5-7 % faster
+  // (config 3 shape, dropout 0.1: 34.8-35.4 against 36.9-37.9 us, two boxes).
   const bool win = win_ok && win_mode != 0 &&
-                   (win_mode == 2 || (mmt::fwd_win_lds_bytes(p.pat.ng, p.tstride) <= 81920 && (p.pat.ng == 0 || desc->S <= 4096)));
+                   (win_mode == 2 || (mmt::fwd_win_lds_bytes(p.pat.ng, p.tstride) <= 81920 && p.pat.ng > 0 && desc->S <= 4096));
   if (win) {
     // rows of the global tokens: at most 16 -> extra workgroups of the window launch (8 rows each, no workspace, no
     // combine launch); more -> the 32-row items of the per-wave kernel + combine, as a launch of their own
