@@ -35,7 +35,15 @@ hipError_t launch_attn_fwd(const FwdParams& p, int, bool, hipStream_t) {
   return hipSuccess;
 }
 hipError_t launch_attn_fwd_band_bf16(const FwdParams& p, hipStream_t st) { hipError_t e = launch_attn_fwd(p, 0, true, st); g_last_kind = 2; return e; }
-hipError_t launch_attn_fwd_win_bf16(const FwdParams& p, hipStream_t) { ++g_launches; g_last_kind = 3; g_last_epoch = p.epoch; return hipSuccess; }
+hipError_t launch_attn_fwd_win_bf16(const FwdParams& p, hipStream_t) {
+  ++g_launches; g_last_kind = 3; g_last_epoch = p.epoch;
+  if (p.rows_parts < 1 || p.rows_parts > 4) { std::fprintf(stderr, "asan driver: rows_parts %d\n", p.rows_parts); std::abort(); }
+  if (p.rows_parts > 1) {                     // the row groups' parts live in the caller's workspace, the ticket in its counters
+    inside(p.walk_part, (size_t)p.B * p.N * p.n_rowblk * p.rows_parts * 8 * 66 * 4, "rows parts");
+    if (!p.sync) { std::fprintf(stderr, "asan driver: split row groups without arrival counters\n"); std::abort(); }
+  }
+  return hipSuccess;
+}
 hipError_t launch_attn_fwd_walk_bf16(const FwdParams& p, int grid, hipStream_t) {
   ++g_launches; g_last_kind = 8; g_last_epoch = p.epoch;
   if (p.pat.ng > 0) inside(p.walk_part, (size_t)p.B * p.N * p.walk_maxseg * 8 * 66 * 4, "walk_part");

@@ -70,7 +70,7 @@ __device__ __forceinline__ float half32_sum(float x) {
 }
 
 template <int REL, bool DROP>
-__device__ __forceinline__ void fwd_rows_body(const FwdParams& p, unsigned char* smem, int bn, int gq) {
+__device__ __forceinline__ void fwd_rows_body(const FwdParams& p, unsigned char* smem, int bn, int gq, int part) {
   using T = __bf16;
 #ifdef MMT_STAMP
   long long* rdbg = (p.dbg && blockIdx.x == 0 && ((threadIdx.x >> 6) & 1) == 0) ? p.dbg + (3 * 4 + (threadIdx.x >> 7)) * 128 : nullptr;
@@ -100,8 +100,12 @@ __device__ __forceinline__ void fwd_rows_body(const FwdParams& p, unsigned char*
   const int m = p.pat.m;
   const int qg0 = p.pat.g0 + 8 * gq, n_q = min(8, p.pat.ng - 8 * gq);
   const int n_tiles = (p.S + 31) >> 5;
-  const int per_wave = (n_tiles + 7) >> 3;
-  const int tw0 = wave * per_wave, tw1 = min(n_tiles, tw0 + per_wave);
+  // this workgroup's share of the keys (rows_parts workgroups per plane and row group: alone, one lived 62-66 k cycles --
+  // under the band workgroups it shares its CU with, as long as the whole launch), then the wave's share of that
+  const int n_parts = p.rows_parts, per_part = (n_tiles + n_parts - 1) / n_parts;
+  const int pt0 = min(n_tiles, part * per_part), pt1 = min(n_tiles, pt0 + per_part);
+  const int per_wave = (pt1 - pt0 + 7) >> 3;
+  const int tw0 = min(pt1, pt0 + wave * per_wave), tw1 = min(pt1, tw0 + per_wave);
 
   const unsigned qs1b = (unsigned)p.qs[1] * 2, ks1b = (unsigned)p.ks[1] * 2, vs1b = (unsigned)p.vs[1] * 2;
   const T* Qb = reinterpret_cast<const T*>(p.q) + (long)b * p.qs[0] + (long)n * p.qs[2];
@@ -327,22 +331,81 @@ __device__ __forceinline__ void fwd_rows_body(const FwdParams& p, unsigned char*
     }
   }
   __syncthreads();
-  if (wave >= n_q) return;
-  {
-    const int qq = wave, q = qg0 + qq, d = lane;
-    float M = -INFINITY;
+  float M = -INFINITY, L = 0.f, acc = 0.f;
+  const int qq = wave, d = lane;
+  if (wave < n_q) {
 #pragma unroll
     for (int w = 0; w < 8; ++w) M = fmaxf(M, comb[w * kCombW + qq]);
-    float L = 0.f, acc = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) {
       const float wgt = __builtin_amdgcn_exp2f(comb[w * kCombW + qq] - M);
       L = fmaf(wgt, comb[w * kCombW + 8 + qq], L);
       acc = fmaf(wgt, comb[w * kCombW + 16 + qq * 64 + d], acc);
     }
+  }
+  if (n_parts == 1) {
+    if (wave < n_q) {
+      const int q = qg0 + qq;
+      T* O = reinterpret_cast<T*>(p.out) + (long)b * p.os[0] + (long)q * p.os[1] + (long)n * p.os[2];
+      O[d] = (T)(acc * (DROP ? p.inv_keep : 1.f) / L);
+      if (p.lse && d == 0) p.lse[((long)b * p.N + n) * p.S + q] = (M + log2f(L)) * kLn2;
+    }
+    return;
+  }
+  // ---- several workgroups per row group: this one's (max, sum, O) of every row goes to the workspace, the plane's last
+  //      arriver (agent-scope ticket on the caller's counter of the plane, left zero) merges the parts of all row groups
+  const int n_groups = p.n_rowblk;
+  float* base = p.walk_part + (size_t)bn * n_groups * n_parts * (8 * 66);
+  if (wave < n_q) {
+    float* mine = base + ((size_t)gq * n_parts + part) * (8 * 66) + qq * 66;
+    __hip_atomic_store(mine + d, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == 0) {
+      __hip_atomic_store(mine + 64, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 65, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  int* flag = reinterpret_cast<int*>(smem + 8 * kWaveB);        // (the table of the rows: dead)
+  if (threadIdx.x == 0) {
+    const unsigned total = (unsigned)(n_groups * n_parts);
+    const unsigned old = __hip_atomic_fetch_add(p.sync + bn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old + 1u == total;
+    if (last) {
+      __hip_atomic_store(p.sync + bn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // left zero for the next call
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    flag[0] = last;
+  }
+  __syncthreads();
+  if (!flag[0]) return;
+  for (int g = 0; g < n_groups; ++g) {
+    const int nq_g = min(8, p.pat.ng - 8 * g);
+    if (wave >= nq_g) continue;
+    const float* src = base + (size_t)g * n_parts * (8 * 66) + qq * 66;
+    float ms[4], ls[4], as[4];                                   // (rows_parts <= 4)
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const float* ps = src + (size_t)min(s2, n_parts - 1) * (8 * 66);
+      ms[s2] = __hip_atomic_load(ps + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ls[s2] = __hip_atomic_load(ps + 65, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      as[s2] = __hip_atomic_load(ps + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    float Mt = -INFINITY;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) if (s2 < n_parts) Mt = fmaxf(Mt, ms[s2]);
+    float Lt = 0.f, At = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const float wgt = s2 < n_parts ? __builtin_amdgcn_exp2f(ms[s2] - Mt) : 0.f;
+      Lt = fmaf(wgt, ls[s2], Lt);
+      At = fmaf(wgt, as[s2], At);
+    }
+    const int q = p.pat.g0 + 8 * g + qq;
     T* O = reinterpret_cast<T*>(p.out) + (long)b * p.os[0] + (long)q * p.os[1] + (long)n * p.os[2];
-    O[d] = (T)(acc * (DROP ? p.inv_keep : 1.f) / L);
-    if (p.lse && d == 0) p.lse[((long)b * p.N + n) * p.S + q] = (M + log2f(L)) * kLn2;
+    O[d] = (T)(At * (DROP ? p.inv_keep : 1.f) / Lt);
+    if (p.lse && d == 0) p.lse[((long)b * p.N + n) * p.S + q] = (Mt + log2f(Lt)) * kLn2;
   }
 }
 
@@ -387,7 +450,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_win_bf16_kernel(const FwdPara
   // The flipped-rows workgroups (n_rowblk per plane) come FIRST in the grid, padded to a multiple of 8 blocks so that
   // the band blocks keep their XCD groups: a rows workgroup lives about as long as half the launch (its 8 waves
   // walk all keys of the plane), so it has to start at time 0 to stay off the tail.
-  const int n_rows_wg = p.n_rowblk * p.B * p.N, n_rows_pad = (n_rows_wg + 7) & ~7;
+  const int n_rows_wg = p.n_rowblk * p.rows_parts * p.B * p.N, n_rows_pad = (n_rows_wg + 7) & ~7;
   if ((int)blockIdx.x < n_rows_pad) {
 #ifdef MMT_STAMP
     if (p.dbg_mode & 32) return;
@@ -399,7 +462,8 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_win_bf16_kernel(const FwdPara
       const int BN = p.B * p.N, i = (int)blockIdx.x;
       int item = i;
       if ((BN & 7) == 0 && (n_rows_wg & 7) == 0) item = (i & 7) * (n_rows_wg >> 3) + (i >> 3);
-      fwd_rows_body<REL, DROP>(p, smem, item / p.n_rowblk, item % p.n_rowblk);
+      const int per_plane = p.n_rowblk * p.rows_parts, in_plane = item % per_plane;
+      fwd_rows_body<REL, DROP>(p, smem, item / per_plane, in_plane / p.rows_parts, in_plane % p.rows_parts);
     }
     return;
   }
@@ -777,7 +841,7 @@ int fwd_win_lds_bytes(int ng, int tstride) {
 }
 
 hipError_t launch_attn_fwd_win_bf16(const FwdParams& p, hipStream_t st) {
-  dim3 grid(p.n_band_blocks + ((p.n_rowblk * p.B * p.N + 7) & ~7));
+  dim3 grid(p.n_band_blocks + ((p.n_rowblk * p.rows_parts * p.B * p.N + 7) & ~7));
   const int lds = fwd_win_lds_bytes(p.pat.ng, p.tstride);
   const bool rel = p.R > 0 && p.pat.id_mode == 1;
   const bool drop = p.drop_thresh != 0;

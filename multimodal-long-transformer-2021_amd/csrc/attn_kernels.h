@@ -34,6 +34,8 @@ struct FwdParams {
   int perm_1d;        // 1-D ids with R >= 2m+1: table columns permuted, fast path allowed
   int lean_rp;        // lean 2-D path: table width (32 | 64) that holds every id that can contribute
   int rows_only;      // lean band kernel: launch holds the global-row items only (the window kernel produced the band rows)
+  int rows_parts;     // window kernel: workgroups per (plane, 8 global rows), each walking 1 / rows_parts of the keys (> 1 needs
+                      // `sync` and `walk_part`: the plane's last arriver merges the parts)
   int tstride;        // window / walk kernels: row stride (floats) of the per-wave relative-score table
   // plane-walk kernel (attn_fwd_walk.hip): runs per plane (walk_nseg, + 1 for the first walk_nhi planes of every XCD
   // group), XCD groups (8 | 1), partial slots per plane; partials of the global rows [B*N][walk_maxseg][8][66] floats;

@@ -105,6 +105,8 @@ Plan make_plan(const mmt_attn_desc* d, bool dense) {
   pl.n_rowblk = pl.split_rows ? (d->mask.n_global + 31) / 32 : 0;
   pl.n_chunks = pl.split_rows ? (n_tiles + kChunkTiles - 1) / kChunkTiles : 0;
   pl.fwd_ws = (size_t)d->B * d->N * pl.n_rowblk * pl.n_chunks * (32 * 64 + 64) * sizeof(float);
+  if (pl.split_rows && d->mask.n_global <= 16)     // window kernel: the row groups' parts (<= 2 groups x 4 parts of 8 x 66 floats per plane)
+    pl.fwd_ws = std::max(pl.fwd_ws, (size_t)d->B * d->N * 2 * 4 * 8 * 66 * sizeof(float));
   if (pl.split_rows && d->mask.n_global <= 8) {    // plane-walk / sliding-window kernels: partials of the global rows per run
     pl.fwd_ws = std::max(pl.fwd_ws, mmt::fwd_walk_workspace_bytes(d->B, d->N, d->S));
     pl.fwd_ws = std::max(pl.fwd_ws, mmt::fwd_pwin_workspace_bytes(d->B, d->N, d->S, 2 * 256));
@@ -143,6 +145,7 @@ int lean2d_width(const mmt::PatternDev& pat, int R, bool dense) {
 
 void fill_common(mmt::FwdParams& p, const mmt_attn_desc* d) {
   std::memset(&p, 0, sizeof(p));
+  p.rows_parts = 1;
   p.B = d->B; p.S = d->S; p.N = d->N; p.R = d->R;
   for (int i = 0; i < 3; ++i) {
     p.qs[i] = d->q_stride[i]; p.ks[i] = d->k_stride[i];
@@ -273,20 +276,35 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
     }
   }
   const bool win_ok = lean && !p.lean_rp && desc->R <= 32 && p.pat.radius <= 64 && p.pat.ng <= 128;
-  // The window kernel's flipped-rows workgroups walk ALL key tiles of their plane (8 waves x S / 256 tiles each): at
-  // S = 8192 one lives longer than the band workgroups of the whole launch take (config 5, g = 8: window 52.7 us,
-  // per-wave 47.1 us per call; at S = 4096: 46.0 against 48.5), so beyond 4096 positions the per-wave kernel keeps
-  // the call unless the window kernel is forced.  Without global tokens the window kernel has nothing to win -- what it
-  // made cheaper is the global tokens -- and the per-wave kernel, whose waves never meet at a barrier, is 5-7 % faster
-  // (config 3 shape, dropout 0.1: 34.8-35.4 against 36.9-37.9 us, two boxes).
+  // The window kernel's flipped-rows workgroups walk the key tiles of their plane, 8 waves x S / 256 tiles each when one
+  // workgroup takes a (plane, 8 rows) group alone: under the band workgroups it shares its CU with it then lives about
+  // as long as the launch at S = 4096 and longer at S = 8192 (config 5, g = 8: window 52.7 us, per-wave 47.1 us per
+  // call).  With the caller's arrival counters (desc->sync) the group is split over the keys -- S / 2048 workgroups, at
+  // most four, merged by the plane's last arriver -- and the window kernel wins at both lengths (config 3: 41.6 against
+  // 44.0 us unsplit and 45.8 per-wave; config 5: 41.8 against 45.9).  Without counters it keeps S <= 4096 only.
+  // Without global tokens the window kernel has nothing to win -- what it made cheaper is the global tokens -- and the
+  // per-wave kernel, whose waves never meet at a barrier, is 5-7 % faster (config 3 shape, dropout 0.1: 34.8-35.4
+  // against 36.9-37.9 us, two boxes).
+  const bool can_split_rows = desc->sync && desc->sync_words >= (uint32_t)(desc->B * desc->N) && workspace;
   const bool win = win_ok && win_mode != 0 &&
-                   (win_mode == 2 || (mmt::fwd_win_lds_bytes(p.pat.ng, p.tstride) <= 81920 && p.pat.ng > 0 && desc->S <= 4096));
+                   (win_mode == 2 || (mmt::fwd_win_lds_bytes(p.pat.ng, p.tstride) <= 81920 && p.pat.ng > 0 &&
+                                      (desc->S <= 4096 || (can_split_rows && p.pat.ng <= 16))));
   if (win) {
     // rows of the global tokens: at most 16 -> extra workgroups of the window launch (8 rows each, no workspace, no
     // combine launch); more -> the 32-row items of the per-wave kernel + combine, as a launch of their own
     const bool rows_in_win = pl.split_rows && p.pat.ng <= 16;
     const int n_rowblk_items = p.n_rowblk;
     p.n_rowblk = rows_in_win ? (p.pat.ng + 7) / 8 : 0;
+    // each (plane, 8 rows) group by up to four workgroups, a quarter of the keys each, merged by the plane's last arriver:
+    // needs the caller's arrival counters (desc->sync); without them one workgroup walks all keys, as until round 4
+    p.rows_parts = 1;
+    if (rows_in_win && can_split_rows) {
+      const int n_tiles = (desc->S + 31) / 32;
+      p.rows_parts = std::max(1, std::min(4, n_tiles / 64));
+      if ((size_t)desc->B * desc->N * p.n_rowblk * p.rows_parts * 8 * 66 * sizeof(float) > workspace_bytes) p.rows_parts = 1;
+      p.walk_part = reinterpret_cast<float*>(workspace);
+      p.sync = desc->sync;
+    }
     e = mmt::launch_attn_fwd_win_bf16(p, st);
     if (e != hipSuccess) return fail(MMT_E_LAUNCH, "window forward launch: %s", hipGetErrorString(e));
     if (!pl.split_rows || rows_in_win) return MMT_OK;
