@@ -61,6 +61,7 @@ enum {
  * variables the library read until ABI 3). */
 #define MMT_TUNE_FWD_WALK 0x01u          /* forward: the plane-walk kernel (attn_fwd_walk.hip) where it covers the shape  */
 #define MMT_TUNE_FWD_PWIN 0x100u         /* forward: the persistent sliding-window kernel (attn_fwd_pwin.hip), likewise */
+#define MMT_TUNE_FWD_ROWS_ONE_WG 0x200u   /* forward, window kernel: one workgroup per (plane, 8 global rows) even with `sync` */
 #define MMT_TUNE_FWD_NO_WIN 0x02u        /* forward: not the window kernel (attn_fwd_win.hip) either: per-wave staging  */
 #define MMT_TUNE_FWD_FORCE_WIN 0x04u     /* forward: window kernel whenever the shape is covered, whatever its LDS need */
 #define MMT_TUNE_BWD_NO_HANDOVER 0x08u   /* backward: the dK/dV pass recomputes P instead of reading the dQ pass's      */

@@ -285,7 +285,8 @@ int mmt_attn_fwd(const mmt_attn_desc* desc, const void* q, const void* k, const 
   // Without global tokens the window kernel has nothing to win -- what it made cheaper is the global tokens -- and the
   // per-wave kernel, whose waves never meet at a barrier, is 5-7 % faster (config 3 shape, dropout 0.1: 34.8-35.4
   // against 36.9-37.9 us, two boxes).
-  const bool can_split_rows = desc->sync && desc->sync_words >= (uint32_t)(desc->B * desc->N) && workspace;
+  const bool can_split_rows = desc->sync && desc->sync_words >= (uint32_t)(desc->B * desc->N) && workspace &&
+                              !(desc->tuning & MMT_TUNE_FWD_ROWS_ONE_WG);
   const bool win = win_ok && win_mode != 0 &&
                    (win_mode == 2 || (mmt::fwd_win_lds_bytes(p.pat.ng, p.tstride) <= 81920 && p.pat.ng > 0 &&
                                       (desc->S <= 4096 || (can_split_rows && p.pat.ng <= 16))));

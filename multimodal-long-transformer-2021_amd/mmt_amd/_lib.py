@@ -21,6 +21,7 @@ MMT_FLAG_ACCUM_REL_GRADS = 2
 # mmt_attn_desc.tuning (include/mmt_attn.h): kernel-selection switches; 0 = the library's defaults
 MMT_TUNE_FWD_WALK = 0x01
 MMT_TUNE_FWD_PWIN = 0x100
+MMT_TUNE_FWD_ROWS_ONE_WG = 0x200
 MMT_TUNE_FWD_NO_WIN = 0x02
 MMT_TUNE_FWD_FORCE_WIN = 0x04
 MMT_TUNE_BWD_NO_HANDOVER = 0x08

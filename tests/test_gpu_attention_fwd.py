@@ -112,10 +112,11 @@ def test_structured_pattern(cfg, dtype):
 def _fwd_kernels():
   from mmt_amd import _lib
   return {'per-wave': _lib.MMT_TUNE_FWD_NO_WIN, 'window': _lib.MMT_TUNE_FWD_FORCE_WIN, 'walk': _lib.MMT_TUNE_FWD_WALK,
+          'window-unsplit-rows': _lib.MMT_TUNE_FWD_FORCE_WIN | _lib.MMT_TUNE_FWD_ROWS_ONE_WG,
           'sliding-window': _lib.MMT_TUNE_FWD_PWIN}
 
 
-@pytest.mark.parametrize('kernel', ['per-wave', 'window', 'walk', 'sliding-window'])
+@pytest.mark.parametrize('kernel', ['per-wave', 'window', 'window-unsplit-rows', 'walk', 'sliding-window'])
 @pytest.mark.parametrize('cfg', [
     dict(B=2, S=256, N=2, R=32, radius=16, g0=200, ng=8, m=12),
     dict(B=2, S=300, N=2, R=32, radius=64, g0=251, ng=8, m=12, valid=[300, 211]),     # ragged, odd global start

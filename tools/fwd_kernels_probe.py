@@ -14,7 +14,7 @@ q, k, v = (torch.randn(B, S, N, D, device='cuda', generator=g).to(torch.bfloat16
 emb = (torch.randn(R, N, D, device='cuda', generator=g) * 0.02).to(torch.bfloat16)
 bias = (torch.randn(R, N, device='cuda', generator=g) * 0.02).to(torch.bfloat16)
 pat = mmt_amd.AttentionPattern(local_radius=cfg['radius'], global_start=cfg['g0'], n_global=cfg['ng'], id_mode=1, max_dist=cfg['m'])
-kinds = {'default': 0, 'sliding window': _lib.MMT_TUNE_FWD_PWIN, 'window': _lib.MMT_TUNE_FWD_FORCE_WIN, 'walk': _lib.MMT_TUNE_FWD_WALK, 'per-wave': _lib.MMT_TUNE_FWD_NO_WIN}
+kinds = {'default': 0, 'sliding window': _lib.MMT_TUNE_FWD_PWIN, 'window': _lib.MMT_TUNE_FWD_FORCE_WIN, 'window, one rows workgroup': _lib.MMT_TUNE_FWD_FORCE_WIN | _lib.MMT_TUNE_FWD_ROWS_ONE_WG, 'walk': _lib.MMT_TUNE_FWD_WALK, 'per-wave': _lib.MMT_TUNE_FWD_NO_WIN}
 call = lambda t: mmt_amd.relative_attention_forward(q, k, v, emb, bias, pattern=pat, dropout_p=pdrop, dropout_seed=12345, tuning=t)
 outs = {n: call(t) for n, t in kinds.items()}
 torch.cuda.synchronize()
