@@ -237,3 +237,34 @@ def test_config5_shape_forward_backward(ng):
   # every row of P sums to 1, so sum_k dV[k] = sum_q dO[q] per head
   dv_sum = tv.grad.float().sum(dim=1)
   assert float((dv_sum - float(S)).abs().max()) < 0.02 * S
+
+
+def test_split_row_groups_long_sequence():
+  """The window kernel's row groups walked by several workgroups (S >= 4096 with the host's arrival counters): two
+  groups of global rows (12 tokens), a ragged batch; against the oracle without dropout, and with dropout against the
+  one-workgroup form and the per-wave kernel (same mask: tests above) -- only summation order may differ."""
+  import mmt_amd
+  from mmt_amd import _lib
+  B, S, N, R = 2, 4096, 1, 32
+  q, k, v, emb, bias = attention_inputs(B, S, N, R, seed=21)
+  q, k, v, emb, bias = (bf16_round(x) for x in (q, k, v, emb, bias))
+  valid = [4096, 3990]
+  pat = mmt_amd.AttentionPattern(local_radius=64, global_start=3971, n_global=12, id_mode=1, max_dist=12)
+  dev = lambda x: torch.from_numpy(x).cuda().to(torch.bfloat16)
+  vl = torch.tensor(valid, dtype=torch.int32, device='cuda:0')
+  args = (dev(q), dev(k), dev(v), dev(emb), dev(bias))
+  out, lse = mmt_amd.relative_attention_forward(*args, pattern=pat, valid_len=vl)
+  mask, ids = dense_side_inputs(B, S, valid, 64, 3971, 12, 1, 12)
+  ref, ref_lse = oa.relative_attention_fwd(q, k, v, emb, bias, mask, ids)
+  got = out.float().cpu().numpy()
+  assert np.isfinite(got).all()
+  assert np.abs(got - ref).max() < BF16_TOL and np.abs(lse.cpu().numpy() - ref_lse).max() < BF16_TOL
+  outs = {}
+  for name, tuning in (('split', 0), ('one', _lib.MMT_TUNE_FWD_FORCE_WIN | _lib.MMT_TUNE_FWD_ROWS_ONE_WG), ('per-wave', _lib.MMT_TUNE_FWD_NO_WIN)):
+    outs[name] = mmt_amd.relative_attention_forward(*args, pattern=pat, valid_len=vl, dropout_p=0.25, dropout_seed=99, tuning=tuning)
+  for name in ('one', 'per-wave'):
+    assert float((outs['split'][0].float() - outs[name][0].float()).abs().max()) < BF16_TOL, name
+    assert float((outs['split'][1] - outs[name][1]).abs().max()) < 1e-3, name
+  # the counters are left zero: a second call gives the same bits
+  again, _ = mmt_amd.relative_attention_forward(*args, pattern=pat, valid_len=vl)
+  assert torch.equal(again, out)
