@@ -157,13 +157,16 @@ int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, const void* 
                               const void* x, int64_t ldx, int32_t M, int32_t N, int64_t K,
                               void* workspace, size_t workspace_bytes, void* stream);
 
-/* Up to eight such products in ONE launch -- the weight gradients of the four Dense layers of one or two encoder blocks
+/* Up to 28 such products in ONE launch -- the weight gradients of the four Dense layers of one to seven encoder blocks
  * (`tape.gradient`, src/tasks/pretraining.py:292-296), which contract the same K = B*S rows.  Alone, the small
  * products need a deep split of K to fill the chip and write one fp32 slab per slice; together two slices
  * suffice for one block (108 tiles at BERT-base dims: 4x less slab traffic) and for two blocks K is not split
- * at all: every tile belongs to one workgroup, which adds it into dw with plain stores (no slabs, no reduce).  Every problem needs M % 256 == 0,
- * N % 256 == 0; K % 64 == 0; the workspace (mmt_wgrad_group_workspace_bytes) is required.  dbias may be NULL
- * per problem.  Results are bitwise those of a fixed-order sum over the slices. */
+ * at all: every tile belongs to one workgroup, which adds it into dw with plain stores (no slabs, no reduce).
+ * With more tiles than compute units (three blocks and up) the tiles go in whole rounds of one workgroup per tile over
+ * the whole K, and only the tail that does not fill a round is split -- into compact per-tile slabs, reduced by a small
+ * second launch (seven blocks: 756 tiles = 2 rounds + 244 unsplit; five: 2 rounds + 28 tiles x 8 slices).
+ * Every problem needs M % 256 == 0, N % 256 == 0; K % 64 == 0; the workspace (mmt_wgrad_group_workspace_bytes, may be
+ * 0 bytes) is required.  dbias may be NULL per problem.  Results are bitwise those of a fixed-order sum over the slices. */
 typedef struct mmt_wgrad_problem {
   float* dw;        /* [M, N] fp32, row stride ldw, accumulated into */
   int64_t ldw;

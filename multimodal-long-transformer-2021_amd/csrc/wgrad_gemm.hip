@@ -18,8 +18,10 @@
 #include "attn_tile.h"
 #include "mmt_err.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 
 namespace mmt {
 
@@ -424,6 +426,91 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_group_kernel(const WgradGrou
   wgrad_dma_body(p, ks, tm, tn);
 }
 
+// ---- more tiles than compute units: whole rounds of UNSPLIT tiles plus a split tail ---------------------------------------
+// A block's four products have 108 tiles: two K slices make 216 workgroups for 256 CUs (84 % of the chip, and every
+// tile goes through two fp32 slabs and a reduce).  With the products of SEVERAL blocks in one launch -- a host that has
+// no gradient exchange to overlap can queue a whole backward pass -- the tiles come in rounds: the first
+// floor(tiles / CUs) * CUs tiles are taken one per workgroup over the whole K and added into dw in place (no slab, no
+// reduce; XCD x owns a contiguous eighth of them, marching K in step as before), the remaining R < CUs tiles are split
+// floor(CUs / R)-way (at most 8) into compact per-tile slabs and reduced by a small launch.  12 blocks: 1296 tiles = 5
+// rounds + 16 tiles x 8 slices; 5 blocks: 540 = 2 rounds + 28 x 8; 7 blocks: 756 = 2 rounds + 244 x 1.
+struct WgradProb { const __bf16* dy; const __bf16* x; float* dw; float* dbias; int ldy, ldx, ldw, M, N, pad; };
+constexpr int kBigMax = 28;
+struct WgradBig {
+  WgradProb q[kBigMax];
+  int tiles_end[kBigMax];
+  int n, K;
+  int full_tiles;                 // tiles [0, full_tiles): one workgroup each, whole K (multiple of 8)
+  int tail_tiles, tail_pad;       // the tiles behind them; tail_tiles * tail_split padded to a multiple of 8 workgroups
+  int tail_split, tail_kps;
+  float* tail_slabs;              // [tail tile][slice][256 x 256]
+  float* tail_bias;               // [tail tile][slice][256]
+};
+__device__ __forceinline__ void big_tile(const WgradBig& g, int t, int& j, int& tm, int& tn) {
+  j = 0;
+  while (j + 1 < g.n && t >= g.tiles_end[j]) ++j;
+  if (j > 0) t -= g.tiles_end[j - 1];
+  const int tiles_m = g.q[j].M >> 8, tiles_n = g.q[j].N >> 8;
+  if (tiles_m < tiles_n) { tn = t / tiles_m; tm = t - tn * tiles_m; }      // (the shorter dimension fastest, as wgrad_dma_group_kernel)
+  else { tm = t / tiles_n; tn = t - tm * tiles_n; }
+}
+__global__ __launch_bounds__(512, 2) void wgrad_dma_big_kernel(const WgradBig g) {
+  // blockIdx -> (XCD x, position i in the XCD's list): the XCD's share of the unsplit tiles first, then its share of the tail
+  const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+  const int full8 = g.full_tiles >> 3, tail8 = g.tail_pad >> 3;
+  int t, ks = 0, tt = -1;
+  if (i < full8) {
+    t = x * full8 + i;
+  } else {
+    const int u = x * tail8 + (i - full8);
+    if (u >= g.tail_tiles * g.tail_split) return;
+    ks = u / g.tail_tiles; tt = u - ks * g.tail_tiles;
+    t = g.full_tiles + tt;
+  }
+  int j, tm, tn;
+  big_tile(g, t, j, tm, tn);
+  const WgradProb& q = g.q[j];
+  WgradParams p;
+  p.dy = q.dy; p.x = q.x; p.dw = q.dw; p.dbias = q.dbias;
+  p.ldy = q.ldy; p.ldx = q.ldx; p.ldw = q.ldw; p.K = g.K;
+  p.tiles_n = q.N >> 8; p.tiles_m = q.M >> 8;
+  if (tt < 0 || g.tail_split == 1) {       // (a tail that fills most of the chip is not split: in place like the rounds)
+    p.M = q.M; p.N = q.N; p.k_per_split = g.K; p.slabs = nullptr; p.bias_part = nullptr;
+  } else {
+    // the tile's own compact slabs: the body addresses [slice][M x N] slabs by (m0, n0) -- with M = N = 256 and the base
+    // moved back by the tile's origin it lands in [tail tile][slice][256 x 256]
+    p.M = 256; p.N = 256; p.k_per_split = g.tail_kps;
+    p.slabs = g.tail_slabs + (size_t)tt * g.tail_split * 65536 - ((long)tm * 65536 + (long)tn * 256);
+    p.bias_part = q.dbias ? g.tail_bias + (size_t)tt * g.tail_split * 256 - (long)tm * 256 : nullptr;
+  }
+  wgrad_dma_body(p, ks, tm, tn);
+}
+// dw tile += its slices in slice order (and dbias of the tn == 0 tiles); grid = 4 x tail tiles, 64 rows each
+__global__ __launch_bounds__(256) void wgrad_tail_reduce_kernel(const WgradBig g) {
+  const int tt = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+  int j, tm, tn;
+  big_tile(g, g.full_tiles + tt, j, tm, tn);
+  const WgradProb& q = g.q[j];
+  const float* slabs = g.tail_slabs + (size_t)tt * g.tail_split * 65536;
+  const int n_slices = (g.K + g.tail_kps - 1) / g.tail_kps;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int row = quarter * 64 + (e >> 6), c4 = (e & 63) * 4;
+    float* o = q.dw + (long)(tm * 256 + row) * q.ldw + tn * 256 + c4;
+    f32x4 a = *reinterpret_cast<const f32x4*>(o);
+    for (int s2 = 0; s2 < n_slices; ++s2) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(slabs + (size_t)s2 * 65536 + row * 256 + c4);
+      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+    }
+    *reinterpret_cast<f32x4*>(o) = a;
+  }
+  if (quarter == 0 && tn == 0 && q.dbias) {
+    const float* bp = g.tail_bias + (size_t)tt * g.tail_split * 256;
+    float a = q.dbias[tm * 256 + threadIdx.x];
+    for (int s2 = 0; s2 < n_slices; ++s2) a += bp[s2 * 256 + threadIdx.x];
+    q.dbias[tm * 256 + threadIdx.x] = a;
+  }
+}
+
 // dw[m][n] += sum_s slabs[s][m][n]   (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* dw, long ldw, const float* slabs, int split, int M, int N,
                                                            float* dbias, const float* bias_part) {
@@ -567,7 +654,7 @@ extern "C" int mmt_wgrad_bias_accumulate(float* dw, int64_t ldw, float* dbias, c
 // ---- grouped launch (see wgrad_dma_group_kernel) --------------------------------------------------------
 namespace {
 bool group_ok(int32_t n, const mmt_wgrad_problem* pr, int64_t K) {
-  if (n < 1 || n > 8 || !pr || K <= 0 || (K % 64)) return false;
+  if (n < 1 || n > mmt::kBigMax || !pr || K <= 0 || (K % 64)) return false;
   for (int i = 0; i < n; ++i) {
     const mmt_wgrad_problem& q = pr[i];
     if (!q.dw || !q.dy || !q.x || q.M <= 0 || q.N <= 0 || (q.M % 256) || (q.N % 256)) return false;
@@ -588,8 +675,40 @@ void group_split(int tiles, int64_t K, int& split, int& kps) {
 }
 }  // namespace
 
+namespace {
+// Rounds of unsplit tiles + a split tail (wgrad_dma_big_kernel): taken when the group has more tiles than compute units
+// (or more problems than the eight of the small form).
+struct BigPlan { int tiles, full, tail, split, kps, pad; };
+BigPlan big_plan(int32_t n, const mmt_wgrad_problem* pr, int64_t K) {
+  BigPlan b{};
+  for (int i = 0; i < n; ++i) b.tiles += (pr[i].M / 256) * (pr[i].N / 256);
+  const int cus = g_cu_budget.load(std::memory_order_relaxed) & ~7;
+  b.full = (b.tiles / cus) * cus;
+  b.tail = b.tiles - b.full;
+  b.split = 1; b.kps = (int)K;
+  if (b.tail > 0) {
+    int split = std::min(8, std::max(1, cus / b.tail));
+    const int max_split = (int)((K + 255) / 256);
+    if (split > max_split) split = max_split;
+    b.kps = (int)(((K + split - 1) / split + 63) / 64 * 64);
+    b.split = (int)((K + b.kps - 1) / b.kps);
+  }
+  b.pad = (b.tail * b.split + 7) & ~7;
+  return b;
+}
+bool use_big(int32_t n, const mmt_wgrad_problem* pr) {
+  int tiles = 0;
+  for (int i = 0; i < n; ++i) tiles += (pr[i].M / 256) * (pr[i].N / 256);
+  return n > 8 || tiles > (g_cu_budget.load(std::memory_order_relaxed) & ~7);
+}
+}  // namespace
+
 extern "C" size_t mmt_wgrad_group_workspace_bytes(int32_t n, const mmt_wgrad_problem* problems, int64_t K) {
   if (!group_ok(n, problems, K)) return 0;
+  if (use_big(n, problems)) {
+    const BigPlan b = big_plan(n, problems, K);
+    return b.split > 1 ? (size_t)b.tail * b.split * (65536 + 256) * sizeof(float) : 0;
+  }
   int tiles = 0;
   size_t elems = 0;
   for (int i = 0; i < n; ++i) { tiles += (problems[i].M / 256) * (problems[i].N / 256); elems += (size_t)problems[i].M * problems[i].N + problems[i].M; }
@@ -601,9 +720,37 @@ extern "C" size_t mmt_wgrad_group_workspace_bytes(int32_t n, const mmt_wgrad_pro
 extern "C" int mmt_wgrad_grouped(int32_t n, const mmt_wgrad_problem* problems, int64_t K, void* workspace,
                                  size_t workspace_bytes, void* stream) {
   if (!group_ok(n, problems, K))
-    return mmt::fail(MMT_E_UNSUPPORTED, "mmt_wgrad_grouped: needs 1..8 problems with M %% 256 == 0, N %% 256 == 0, K %% 64 == 0, 16-byte aligned operands");
+    return mmt::fail(MMT_E_UNSUPPORTED, "mmt_wgrad_grouped: needs 1..28 problems with M %% 256 == 0, N %% 256 == 0, K %% 64 == 0, 16-byte aligned operands");
   const size_t need = mmt_wgrad_group_workspace_bytes(n, problems, K);
   if (need > 0 && (!workspace || workspace_bytes < need)) return mmt::fail(MMT_E_WORKSPACE, "mmt_wgrad_grouped: workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
+  if (use_big(n, problems)) {
+    const BigPlan b = big_plan(n, problems, K);
+    mmt::WgradBig g;
+    std::memset(&g, 0, sizeof(g));
+    g.n = n; g.K = (int)K;
+    int run = 0;
+    for (int i = 0; i < mmt::kBigMax; ++i) {
+      const mmt_wgrad_problem& q = problems[i < n ? i : n - 1];
+      mmt::WgradProb& w = g.q[i];
+      w.dy = (const __bf16*)q.dy; w.x = (const __bf16*)q.x; w.dw = q.dw; w.dbias = q.dbias;
+      w.ldy = (int)q.ldy; w.ldx = (int)q.ldx; w.ldw = (int)q.ldw; w.M = q.M; w.N = q.N;
+      if (i < n) run += (q.M / 256) * (q.N / 256);
+      g.tiles_end[i] = run;
+    }
+    g.full_tiles = b.full; g.tail_tiles = b.tail; g.tail_pad = b.pad; g.tail_split = b.split; g.tail_kps = b.kps;
+    g.tail_slabs = b.split > 1 ? (float*)workspace : nullptr;
+    g.tail_bias = g.tail_slabs ? g.tail_slabs + (size_t)b.tail * b.split * 65536 : nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const int lds = 2 * mmt::kDmaStageBytes;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mmt::wgrad_dma_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(mmt::wgrad_dma_big_kernel, dim3(b.full + b.pad), dim3(512), lds, st, g);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && b.tail > 0 && b.split > 1) {
+      hipLaunchKernelGGL(mmt::wgrad_tail_reduce_kernel, dim3(4 * b.tail), dim3(256), 0, st, g);
+      e = hipGetLastError();
+    }
+    return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_wgrad_grouped: %s", hipGetErrorString(e));
+  }
   mmt::WgradGroup g;
   g.n = n;
   int tiles = 0;

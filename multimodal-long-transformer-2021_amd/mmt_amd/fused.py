@@ -426,6 +426,12 @@ def _wgrad_groupable(dw, dy, x, dbias) -> bool:
 # MMT_WGRAD_SIDE_STREAM; with the grouped launch the two measured the same -- 15.93 vs 15.98 ms per step over
 # four same-box pairs -- and the form was removed in round 4.)
 _WG_GROUP = 4
+# Without a gradient exchange to overlap (no parameter carries a reducer's hooks) nothing needs a block's gradients before
+# the backward pass ends, and the more products one launch holds the better its tiles fill the chip: 28 products (seven
+# blocks, 756 tiles = 2.95 rounds of 256 workgroups with K unsplit) or what is left when backward ends (the other five
+# blocks of a 12-layer encoder: 540 tiles = 2 rounds + 28 tiles split 8-way) -- against 216 workgroups on 256 CUs and two
+# fp32 slabs per tile for one block alone (csrc/wgrad_gemm.hip: wgrad_dma_big_kernel).
+_WG_GROUP_ALONE = 28
 
 
 def _launch_wgrad_group(items, device, stream) -> None:
@@ -499,7 +505,8 @@ def wgrad_accumulate_deferred_(dw, dy, x, dbias, notify) -> bool:
   for prm in notify:
     prm._mmt_grad_deferred = True
   entry[1].append((dw, dy, x, dbias, tuple(notify)))
-  if len(entry[1]) >= _WG_GROUP:
+  exchanged = any(getattr(prm, '_mmt_grad_ready_hooks', ()) for item in entry[1] for prm in item[4])
+  if len(entry[1]) >= (_WG_GROUP if exchanged else _WG_GROUP_ALONE):
     _flush_wgrad_deferred(device)
   return True
 
