@@ -80,6 +80,17 @@ int mmt_residual_block_bwd(const mmt_rows_desc* desc, const void* dx_new_in, con
 int mmt_colsum_reduce(const mmt_rows_desc* desc, int32_t kind, const void* workspace, float* o0, float* o1,
                       float* o2, void* stream);
 
+/* The same for up to 48 deferred reduces in ONE launch (a host that needs no parameter gradient before the backward
+ * pass ends queues them: ~32 five-microsecond launches per step otherwise).  rows / H / kind / accumulate as in the
+ * desc and call they stand for. */
+typedef struct mmt_colsum_item {
+  const void* workspace;
+  float* o0; float* o1; float* o2;
+  int64_t rows;
+  int32_t H, kind, accumulate, reserved;
+} mmt_colsum_item;
+int mmt_colsum_reduce_batch(int32_t n, const mmt_colsum_item* items, void* stream);
+
 /* y = gelu_tanh(u + bias)   (DenseLayers hidden activation; rows x H with H = intermediate_size) */
 int mmt_bias_gelu_fwd(const mmt_rows_desc* desc, const void* u, const float* bias, void* y,
                       void* stream);

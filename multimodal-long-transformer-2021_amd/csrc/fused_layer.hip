@@ -16,6 +16,7 @@
 #include <cstdio>
 
 #include "layer_common.h"
+#include <cstring>
 #include "mmt_err.h"
 
 namespace mmt {
@@ -243,11 +244,10 @@ __global__ __launch_bounds__(256, (W * NCH <= 12 ? 4 : 1)) void resid_ln_bwd_ker
 // groups had 36 workgroups for the 3 x 768 sums of a residual block -- 36 of 256 CUs reading a 9.4 MB slab:
 // 12 us; 144 narrower workgroups take a third of that.)
 constexpr int kCsCols = 16, kCsGroups = 64;
-__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, int nblocks, int ksets, int H,
-                                                             float* o0, float* o1, float* o2, int accumulate) {
-  __shared__ float red[kCsGroups][kCsCols];
+__device__ __forceinline__ void colsum_reduce_body(int blk, const float* part, int nblocks, int ksets, int H,
+                                                   float* o0, float* o1, float* o2, int accumulate, float (*red)[kCsCols]) {
   const int c = threadIdx.x & (kCsCols - 1), grp = threadIdx.x / kCsCols;
-  const int idx = blockIdx.x * kCsCols + c;
+  const int idx = blk * kCsCols + c;
   const int total = ksets * H;
   const int per = (nblocks + kCsGroups - 1) / kCsGroups;
   const int lo = grp * per, hi = min(nblocks, lo + per);
@@ -272,6 +272,29 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, 
     float* dst = set == 0 ? o0 : (set == 1 ? o1 : o2);
     dst[col] = accumulate ? dst[col] + s : s;
   }
+}
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, int nblocks, int ksets, int H,
+                                                             float* o0, float* o1, float* o2, int accumulate) {
+  __shared__ float red[kCsGroups][kCsCols];
+  colsum_reduce_body(blockIdx.x, part, nblocks, ksets, H, o0, o1, o2, accumulate, red);
+}
+// The reduces of many *_bwd calls (defer_reduce) in ONE launch: workgroups [blocks_end[j-1], blocks_end[j]) belong to
+// item j.  A replayed step holds ~32 of these 5-us launches (0.18 ms); a host with nothing waiting for the parameter
+// gradients before backward ends queues them and launches once.
+constexpr int kCsBatchMax = 48;
+struct ColsumBatch {
+  const float* part[kCsBatchMax];
+  float* o0[kCsBatchMax]; float* o1[kCsBatchMax]; float* o2[kCsBatchMax];
+  int nblocks[kCsBatchMax], H[kCsBatchMax], blocks_end[kCsBatchMax];
+  unsigned char ksets[kCsBatchMax], accumulate[kCsBatchMax];
+  int n;
+};
+__global__ __launch_bounds__(1024) void colsum_reduce_batch_kernel(const ColsumBatch g) {
+  __shared__ float red[kCsGroups][kCsCols];
+  int j = 0;
+  while (j + 1 < g.n && (int)blockIdx.x >= g.blocks_end[j]) ++j;
+  const int blk = (int)blockIdx.x - (j ? g.blocks_end[j - 1] : 0);
+  colsum_reduce_body(blk, g.part[j], g.nblocks[j], g.ksets[j], g.H[j], g.o0[j], g.o1[j], g.o2[j], g.accumulate[j], red);
 }
 
 // Column sums of a [rows, C] matrix with any row stride (the bias gradient of a Dense layer whose output has no
@@ -304,6 +327,11 @@ __global__ __launch_bounds__(256) void colsum_pairs_kernel(const T* x, long ld, 
   for (; row < rows; row += step) { float u, v; load2(row, u, v); a0 += u; a1 += v; }
   part[(long)blockIdx.y * C + c] = a0;
   if (two) part[(long)blockIdx.y * C + c + 1] = a1;
+}
+
+hipError_t launch_colsum_reduce_batch(const ColsumBatch& g, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_reduce_batch_kernel, dim3(g.blocks_end[g.n - 1]), dim3(1024), 0, st, g);
+  return hipGetLastError();
 }
 
 hipError_t launch_colsum_reduce(const float* part, int nblocks, int ksets, int H, float* o0, float* o1,
@@ -685,6 +713,29 @@ int mmt_colsum_reduce(const mmt_rows_desc* d, int32_t kind, const void* ws, floa
   if ((ksets >= 2 && !o1) || (ksets >= 3 && !o2)) return lfail(MMT_E_INVALID, "mmt_colsum_reduce: output missing");
   hipError_t e = mmt::launch_colsum_reduce((const float*)ws, nblocks, ksets, d->H, o0, o1, o2, d->accumulate, (hipStream_t)stream);
   return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_colsum_reduce: %s", hipGetErrorString(e));
+}
+
+int mmt_colsum_reduce_batch(int32_t n, const mmt_colsum_item* items, void* stream) {
+  if (n < 1 || n > mmt::kCsBatchMax || !items) return lfail(MMT_E_INVALID, "mmt_colsum_reduce_batch: needs 1..%d items", mmt::kCsBatchMax);
+  mmt::ColsumBatch g;
+  std::memset(&g, 0, sizeof(g));
+  g.n = n;
+  int end = 0;
+  for (int i = 0; i < n; ++i) {
+    const mmt_colsum_item& it = items[i];
+    if (!it.workspace || !it.o0 || it.kind < 0 || it.kind > 3 || it.rows <= 0 || it.H <= 0 || (it.H & 7) || it.H > 8192)
+      return lfail(MMT_E_INVALID, "mmt_colsum_reduce_batch: bad item %d", i);
+    const int ksets = it.kind == 0 ? 2 : (it.kind == 1 ? 3 : 1);
+    if ((ksets >= 2 && !it.o1) || (ksets >= 3 && !it.o2)) return lfail(MMT_E_INVALID, "mmt_colsum_reduce_batch: output missing in item %d", i);
+    mmt_rows_desc d{}; d.rows = it.rows; d.H = it.H;
+    g.part[i] = (const float*)it.workspace; g.o0[i] = it.o0; g.o1[i] = it.o1; g.o2[i] = it.o2;
+    g.nblocks[i] = it.kind == 3 ? (int)(it.rows < kGeluRowSplit ? it.rows : kGeluRowSplit) : row_blocks(&d);
+    g.H[i] = it.H; g.ksets[i] = (unsigned char)ksets; g.accumulate[i] = it.accumulate ? 1 : 0;
+    end += (ksets * it.H + mmt::kCsCols - 1) / mmt::kCsCols;
+    g.blocks_end[i] = end;
+  }
+  hipError_t e = mmt::launch_colsum_reduce_batch(g, (hipStream_t)stream);
+  return e == hipSuccess ? MMT_OK : lfail(MMT_E_LAUNCH, "mmt_colsum_reduce_batch: %s", hipGetErrorString(e));
 }
 
 int mmt_grad_clip_scale(int32_t n_slabs, const float* const* slabs, const int64_t* sizes, float max_norm,

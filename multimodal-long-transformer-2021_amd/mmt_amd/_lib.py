@@ -34,7 +34,7 @@ EXPORTS = ('mmt_abi_version', 'mmt_last_error', 'mmt_write_step_scalars', 'mmt_w
            'mmt_attn_bwd', 'mmt_side_inputs',
            # include/mmt_layer.h
            'mmt_layer_workspace_bytes', 'mmt_ln_fwd', 'mmt_ln_bwd', 'mmt_residual_block_fwd',
-           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_colsum_reduce', 'mmt_accumulate_grad', 'mmt_grad_clip_scale', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
+           'mmt_residual_block_bwd', 'mmt_bias_gelu_fwd', 'mmt_bias_gelu_bwd', 'mmt_colsum_reduce', 'mmt_colsum_reduce_batch', 'mmt_accumulate_grad', 'mmt_grad_clip_scale', 'mmt_adamw_step', 'mmt_wgrad_accumulate',
            'mmt_wgrad_bias_accumulate', 'mmt_wgrad_grouped', 'mmt_wgrad_group_workspace_bytes', 'mmt_wgrad_workspace_bytes', 'mmt_wgrad_set_cu_budget', 'mmt_embed_fwd', 'mmt_embed_bwd',
            'mmt_embed_workspace_bytes', 'mmt_xent_fwd', 'mmt_xent_fwd_argmax', 'mmt_xent_bwd', 'mmt_xent_bwd_scaled', 'mmt_weighted_loss', 'mmt_colsum', 'mmt_colsum_workspace_bytes', 'mmt_ln_bwd_add', 'mmt_ffn_gelu_gemm', 'mmt_ffn_dgelu_gemm', 'mmt_ffn_set_cu_budget')
 
@@ -84,6 +84,12 @@ class WgradProblem(ctypes.Structure):
   _fields_ = [('dw', ctypes.c_void_p), ('ldw', ctypes.c_int64), ('dbias', ctypes.c_void_p), ('dy', ctypes.c_void_p),
               ('ldy', ctypes.c_int64), ('x', ctypes.c_void_p), ('ldx', ctypes.c_int64), ('M', ctypes.c_int32),
               ('N', ctypes.c_int32)]
+
+
+class ColsumItem(ctypes.Structure):
+  _fields_ = [('workspace', ctypes.c_void_p), ('o0', ctypes.c_void_p), ('o1', ctypes.c_void_p), ('o2', ctypes.c_void_p),
+              ('rows', ctypes.c_int64), ('H', ctypes.c_int32), ('kind', ctypes.c_int32), ('accumulate', ctypes.c_int32),
+              ('reserved', ctypes.c_int32)]
 
 
 class MmtError(RuntimeError):
@@ -149,6 +155,8 @@ def lib() -> ctypes.CDLL:
   L.mmt_bias_gelu_bwd.argtypes = [rd] + [vp] * 6 + [ctypes.c_size_t, vp]
   L.mmt_colsum_reduce.restype = ctypes.c_int
   L.mmt_colsum_reduce.argtypes = [rd, ctypes.c_int32, vp, vp, vp, vp, vp]
+  L.mmt_colsum_reduce_batch.restype = ctypes.c_int
+  L.mmt_colsum_reduce_batch.argtypes = [ctypes.c_int32, ctypes.POINTER(ColsumItem), vp]
   L.mmt_wgrad_accumulate.restype = ctypes.c_int
   L.mmt_wgrad_accumulate.argtypes = [vp, ctypes.c_int64, vp, ctypes.c_int64, vp, ctypes.c_int64, ctypes.c_int32,
                                      ctypes.c_int32, ctypes.c_int64, vp, ctypes.c_size_t, vp]

@@ -93,6 +93,55 @@ def _finish(param, buf, direct):
   return None
 
 
+# ---- column-sum reduces of a backward pass in one launch -------------------------------------------------------------
+# Every *_bwd kernel below leaves per-workgroup partial sums of its parameter gradients (dbias / dgamma / dbeta) in its
+# workspace and a 5-us reduce launch folds them -- ~32 of those per step.  When the gradients go straight into fp32
+# masters and nothing waits for them before the backward pass ends (no parameter carries a reducer's hooks), the
+# reduces are queued (desc.defer_reduce; the workspaces stay alive in the queue) and launched ONCE by an engine callback
+# at the end of backward (`mmt_colsum_reduce_batch`).
+_CS_MAX = 48
+_cs_deferred = {}          # device -> (graph-task id, [(workspace, rows, H, kind, outs)])
+
+
+def _defer_colsum_ok(direct: bool, *params) -> bool:
+  return (direct and grouping_is_safe()
+          and not any(getattr(p, '_mmt_grad_ready_hooks', ()) for p in params if p is not None))
+
+
+def _flush_colsum(device) -> None:
+  entry = _cs_deferred.pop(device, None)
+  if not entry or not entry[1]:
+    return
+  items = entry[1]
+  arr = (_lib.ColsumItem * len(items))()
+  for q, (ws, rows, H, kind, outs) in zip(arr, items):
+    o = list(outs) + [None] * (3 - len(outs))
+    q.workspace, q.o0, q.o1, q.o2 = ws.data_ptr(), _p(o[0]), _p(o[1]), _p(o[2])
+    q.rows, q.H, q.kind, q.accumulate = rows, H, kind, 1
+  with torch.cuda.device(device):
+    _lib.check(_lib.lib().mmt_colsum_reduce_batch(len(items), arr, torch.cuda.current_stream(device).cuda_stream))
+
+
+def _flush_all_colsum():
+  for device in list(_cs_deferred):
+    _flush_colsum(device)
+
+
+def _defer_colsum(ws, rows: int, H: int, kind: int, outs) -> None:
+  device = ws.device
+  gid = _graph_task_id()
+  entry = _cs_deferred.get(device)
+  if entry is not None and entry[0] != gid:              # left behind by a backward pass that raised: not ours to launch
+    _cs_deferred.pop(device)
+    entry = None
+  if entry is None:
+    entry = _cs_deferred[device] = (gid, [])
+    torch.autograd.Variable._execution_engine.queue_callback(_flush_all_colsum)    # end of this backward pass
+  entry[1].append((ws, rows, H, kind, tuple(outs)))
+  if len(entry[1]) >= _CS_MAX:
+    _flush_colsum(device)          # (a later item opens a new entry and queues another callback: harmless)
+
+
 class _LayerNormFn(torch.autograd.Function):
 
   @staticmethod
@@ -125,10 +174,13 @@ class _LayerNormFn(torch.autograd.Function):
       dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
     d = _desc(x2, ctx.eps)
     d.accumulate = int(direct)
+    d.defer_reduce = int(_defer_colsum_ok(direct, gamma_p, beta_p))
     ws = _ws(d, x2)
     with torch.cuda.device(x2.device):
       _lib.check(_lib.lib().mmt_ln_bwd(d, _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(dx), _p(dg),
                                        _p(db), _p(ws), ws.numel(), _stream(x2)))
+    if d.defer_reduce:
+      _defer_colsum(ws, x2.shape[0], x2.shape[1], 0, (dg, db))
     return dx.view(ctx.shape), _finish(gamma_p, dg, direct), _finish(beta_p, db, direct), None
 
 
@@ -175,10 +227,13 @@ class _LayerNormKeepFn(torch.autograd.Function):
       dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
     d = _desc(x2, ctx.eps)
     d.accumulate = int(direct)
+    d.defer_reduce = int(_defer_colsum_ok(direct, gamma_p, beta_p))
     ws = _ws(d, x2)
     with torch.cuda.device(x2.device):
       _lib.check(_lib.lib().mmt_ln_bwd_add(d, _p(dy2), _p(x2), _p(gamma), _p(mean), _p(rstd), _p(din), _p(dx), _p(dg),
                                            _p(db), _p(ws), ws.numel(), _stream(x2)))
+    if d.defer_reduce:
+      _defer_colsum(ws, x2.shape[0], x2.shape[1], 0, (dg, db))
     return dx.view(ctx.shape), _finish(gamma_p, dg, direct), _finish(beta_p, db, direct), None
 
 
@@ -235,11 +290,14 @@ class _ResidualBlockFn(torch.autograd.Function):
       db = torch.empty_like(gamma) if has_ln else None
     d = _desc(x_new, eps, p, seed)
     d.accumulate = int(direct)
+    d.defer_reduce = int(_defer_colsum_ok(direct, bias_p, gamma_p, beta_p))
     ws = _ws(d, x_new)
     with torch.cuda.device(x_new.device):
       _lib.check(_lib.lib().mmt_residual_block_bwd(
           d, _p(dxn), _p(dh2), _p(x_new), _p(gamma), _p(mean), _p(rstd), _p(d_o), _p(dx), _p(dbias),
           _p(dg), _p(db), _p(ws), ws.numel(), _stream(x_new)))
+    if d.defer_reduce:
+      _defer_colsum(ws, x_new.shape[0], x_new.shape[1], 1 if has_ln else 2, (dbias, dg, db) if has_ln else (dbias,))
     return (d_o.view(shape), _finish(bias_p, dbias, direct), dx.view(shape),
             _finish(gamma_p, dg, direct) if has_ln else None,
             _finish(beta_p, db, direct) if has_ln else None, None, None, None)
@@ -275,10 +333,13 @@ class _BiasGeluFn(torch.autograd.Function):
     dbias, direct = _grad_target(ctx.param, bias)
     d = _desc(u2)
     d.accumulate = int(direct)
+    d.defer_reduce = int(_defer_colsum_ok(direct, ctx.param))
     ws = _ws(d, u2)
     with torch.cuda.device(u2.device):
       _lib.check(_lib.lib().mmt_bias_gelu_bwd(d, _p(dy2), _p(u2), _p(bias), _p(du), _p(dbias), _p(ws),
                                               ws.numel(), _stream(u2)))
+    if d.defer_reduce:
+      _defer_colsum(ws, u2.shape[0], u2.shape[1], 3, (dbias,))
     return du.view(ctx.shape), _finish(ctx.param, dbias, direct)
 
 
@@ -475,6 +536,7 @@ def reset_host_queues() -> None:
   """Forgets every weight-gradient product a backward pass has queued but not launched.  For a step that was ABANDONED half-way (a graph capture that raised inside backward, `graphed.py`): its
   queued products point at activations of a step that never ran; the retry must not launch them."""
   _wg_deferred.clear()
+  _cs_deferred.clear()
 
 
 def _flush_all_deferred():

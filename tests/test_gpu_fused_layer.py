@@ -483,3 +483,38 @@ def test_colsum_matches_fp64_sum(rows, C, pad, dtype):
   fused.colsum(x, out=acc)
   assert float((acc.double() - 3.0 - want).abs().max()) < tol
   assert torch.equal(got, fused.colsum(x))
+
+
+def test_deferred_column_sum_reduces_equal_the_immediate_ones(monkeypatch):
+  """Parameter gradients that go straight into fp32 masters with nobody waiting for them: the column-sum reduces of a
+  backward pass are queued and launched once at its end (`mmt_colsum_reduce_batch`) -- same partials, same fixed-order
+  sums as the per-call launches, so the same bits; more items than one batch holds are split."""
+  from mmt_amd import fused
+  torch.manual_seed(5)
+  rows, H = 512, 256
+
+  def run(defer, n_blocks):
+    torch.manual_seed(6)
+    monkeypatch.setattr(fused, '_defer_colsum_ok', (lambda direct, *p: direct) if defer else (lambda direct, *p: False))
+    params = []
+    x = torch.randn(2, rows // 2, H, device='cuda', dtype=torch.bfloat16, requires_grad=True)
+    h = x
+    for _ in range(n_blocks):
+      bias = torch.nn.Parameter(torch.randn(H, device='cuda') * 0.1)
+      gamma = torch.nn.Parameter(torch.rand(H, device='cuda') + 0.5)
+      beta = torch.nn.Parameter(torch.randn(H, device='cuda') * 0.1)
+      b2 = torch.nn.Parameter(torch.randn(H, device='cuda') * 0.1)
+      for prm in (bias, gamma, beta, b2):
+        prm.grad = torch.full_like(prm, 0.25)                   # fp32 masters with something in them already
+      params += [bias, gamma, beta, b2]
+      xn, hh = fused.residual_block(h * 0.5, bias, h, gamma, beta, 1e-12, 0.1, 77)
+      h = fused.bias_gelu(hh, b2) + xn
+    h.float().square().mean().backward()
+    torch.cuda.synchronize()
+    assert not fused._cs_deferred
+    return [prm.grad.clone() for prm in params] + [x.grad.clone()]
+
+  for n_blocks in (3, 30):                                      # 30 blocks: 60 reduces, more than one batch of 48
+    a, b = run(False, n_blocks), run(True, n_blocks)
+    for u, v in zip(a, b):
+      assert torch.equal(u, v)
