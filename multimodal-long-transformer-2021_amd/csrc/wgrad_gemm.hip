@@ -485,25 +485,30 @@ __global__ __launch_bounds__(512, 2) void wgrad_dma_big_kernel(const WgradBig g)
   }
   wgrad_dma_body(p, ks, tm, tn);
 }
-// dw tile += its slices in slice order (and dbias of the tn == 0 tiles); grid = 4 x tail tiles, 64 rows each
+// dw tile += its slices in slice order (and dbias of the tn == 0 tiles); grid = 16 x tail tiles, 16 rows each (with 4 x
+// tail tiles -- 112 workgroups walking their slices one dependent load after the other -- the launch took 47 us for 57 MB)
 __global__ __launch_bounds__(256) void wgrad_tail_reduce_kernel(const WgradBig g) {
-  const int tt = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+  const int tt = blockIdx.x >> 4, part = blockIdx.x & 15;
   int j, tm, tn;
   big_tile(g, g.full_tiles + tt, j, tm, tn);
   const WgradProb& q = g.q[j];
   const float* slabs = g.tail_slabs + (size_t)tt * g.tail_split * 65536;
   const int n_slices = (g.K + g.tail_kps - 1) / g.tail_kps;
-  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-    const int row = quarter * 64 + (e >> 6), c4 = (e & 63) * 4;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int e = it * 256 + threadIdx.x;
+    const int row = part * 16 + (e >> 6), c4 = (e & 63) * 4;
     float* o = q.dw + (long)(tm * 256 + row) * q.ldw + tn * 256 + c4;
     f32x4 a = *reinterpret_cast<const f32x4*>(o);
-    for (int s2 = 0; s2 < n_slices; ++s2) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(slabs + (size_t)s2 * 65536 + row * 256 + c4);
-      a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
-    }
+    f32x4 b[8];                                                    // (tail_split <= 8: every slice's load in flight)
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2)
+      b[s2] = s2 < n_slices ? *reinterpret_cast<const f32x4*>(slabs + (size_t)s2 * 65536 + row * 256 + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 8; ++s2) { a[0] += b[s2][0]; a[1] += b[s2][1]; a[2] += b[s2][2]; a[3] += b[s2][3]; }
     *reinterpret_cast<f32x4*>(o) = a;
   }
-  if (quarter == 0 && tn == 0 && q.dbias) {
+  if (part == 0 && tn == 0 && q.dbias) {
     const float* bp = g.tail_bias + (size_t)tt * g.tail_split * 256;
     float a = q.dbias[tm * 256 + threadIdx.x];
     for (int s2 = 0; s2 < n_slices; ++s2) a += bp[s2 * 256 + threadIdx.x];
@@ -746,7 +751,7 @@ extern "C" int mmt_wgrad_grouped(int32_t n, const mmt_wgrad_problem* problems, i
     hipLaunchKernelGGL(mmt::wgrad_dma_big_kernel, dim3(b.full + b.pad), dim3(512), lds, st, g);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && b.tail > 0 && b.split > 1) {
-      hipLaunchKernelGGL(mmt::wgrad_tail_reduce_kernel, dim3(4 * b.tail), dim3(256), 0, st, g);
+      hipLaunchKernelGGL(mmt::wgrad_tail_reduce_kernel, dim3(16 * b.tail), dim3(256), 0, st, g);
       e = hipGetLastError();
     }
     return e == hipSuccess ? MMT_OK : mmt::fail(MMT_E_LAUNCH, "mmt_wgrad_grouped: %s", hipGetErrorString(e));
